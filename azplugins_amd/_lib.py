@@ -1,0 +1,193 @@
+"""ctypes binding of ``libazp.so`` (the C ABI declared in ``include/azp.h``).
+
+The product path has no CPU fallback: if the HIP library is missing or a call
+fails, an exception is raised.
+"""
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libazp.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+
+class AzpError(RuntimeError):
+    pass
+
+
+# ---------------------------------------------------------------------------
+# structs (field order = include/azp.h)
+# ---------------------------------------------------------------------------
+class Box(C.Structure):
+    _fields_ = [("L", C.c_double * 3), ("tilt", C.c_double * 3), ("periodic", C.c_int32 * 3), ("_pad", C.c_int32)]
+
+
+class PairArgs(C.Structure):
+    _fields_ = [
+        ("d_force", C.c_void_p),
+        ("d_virial", C.c_void_p),
+        ("virial_pitch", C.c_uint64),
+        ("N", C.c_uint32),
+        ("n_max", C.c_uint32),
+        ("d_pos", C.c_void_p),
+        ("box", Box),
+        ("d_n_neigh", C.c_void_p),
+        ("d_nlist", C.c_void_p),
+        ("d_head_list", C.c_void_p),
+        ("d_rcutsq", C.c_void_p),
+        ("d_ronsq", C.c_void_p),
+        ("size_nlist", C.c_uint64),
+        ("ntypes", C.c_uint32),
+        ("shift_mode", C.c_uint32),
+        ("compute_virial", C.c_uint32),
+        ("block_size", C.c_uint32),
+        ("threads_per_particle", C.c_uint32),
+        ("_pad", C.c_uint32),
+        ("r_list_max", C.c_double),
+    ]
+
+
+class DPDArgs(C.Structure):
+    _fields_ = [
+        ("pair", PairArgs),
+        ("d_vel", C.c_void_p),
+        ("d_tag", C.c_void_p),
+        ("timestep", C.c_uint64),
+        ("deltaT", C.c_double),
+        ("T", C.c_double),
+        ("seed", C.c_uint16),
+        ("_pad", C.c_uint16 * 3),
+    ]
+
+
+class AnisoArgs(C.Structure):
+    _fields_ = [("pair", PairArgs), ("d_orientation", C.c_void_p), ("d_torque", C.c_void_p)]
+
+
+class BondArgs(C.Structure):
+    _fields_ = [
+        ("d_force", C.c_void_p),
+        ("d_virial", C.c_void_p),
+        ("virial_pitch", C.c_uint64),
+        ("N", C.c_uint32),
+        ("n_max", C.c_uint32),
+        ("d_pos", C.c_void_p),
+        ("box", Box),
+        ("d_gpu_bondlist", C.c_void_p),
+        ("d_gpu_bond_pos", C.c_void_p),
+        ("d_gpu_n_bonds", C.c_void_p),
+        ("pitch", C.c_uint64),
+        ("n_bond_types", C.c_uint32),
+        ("compute_virial", C.c_uint32),
+        ("block_size", C.c_uint32),
+        ("_pad", C.c_uint32),
+    ]
+
+
+class CellGrid(C.Structure):
+    _fields_ = [("lo", C.c_double * 3), ("width", C.c_double * 3), ("dim", C.c_uint32 * 3), ("periodic", C.c_int32 * 3)]
+
+
+class NlistArgs(C.Structure):
+    _fields_ = [
+        ("N", C.c_uint32),
+        ("n_total", C.c_uint32),
+        ("d_pos", C.c_void_p),
+        ("box", Box),
+        ("grid", CellGrid),
+        ("ntypes", C.c_uint32),
+        ("_pad", C.c_uint32),
+        ("d_rlistsq", C.c_void_p),
+        ("d_cell_of", C.c_void_p),
+        ("d_cell_sorted", C.c_void_p),
+        ("d_order", C.c_void_p),
+        ("d_cell_start", C.c_void_p),
+        ("d_n_excl", C.c_void_p),
+        ("d_excl", C.c_void_p),
+        ("excl_pitch", C.c_uint64),
+        ("d_n_neigh", C.c_void_p),
+        ("d_head_list", C.c_void_p),
+        ("d_nlist", C.c_void_p),
+    ]
+
+
+# every symbol include/azp.h declares: name -> (restype, argtypes)
+_D = C.c_double
+_PD = C.POINTER(C.c_double)
+_PI = C.POINTER(C.c_int)
+_VP = C.c_void_p
+SYMBOLS = {
+    "azp_plj_params_make": (None, [_D] * 3 + [_VP]),
+    "azp_plj_params_unpack": (None, [_VP] + [_PD] * 3),
+    "azp_colloid_params_make": (None, [_D] * 4 + [_VP]),
+    "azp_colloid_params_unpack": (None, [_VP] + [_PD] * 4),
+    "azp_tpm_params_make": (None, [_D] * 5 + [C.c_int, _VP]),
+    "azp_tpm_params_unpack": (None, [_VP] + [_PD] * 5 + [_PI]),
+    "azp_dw_params_make": (None, [_D] * 4 + [_VP]),
+    "azp_dw_params_unpack": (None, [_VP] + [_PD] * 4),
+    "azp_quartic_params_make": (None, [_D] * 8 + [_VP]),
+    "azp_quartic_params_unpack": (None, [_VP] + [_PD] * 8),
+    "azp_pair_forces_perturbed_lennard_jones": (C.c_int, [C.POINTER(PairArgs), _VP, _VP]),
+    "azp_pair_forces_hertz": (C.c_int, [C.POINTER(PairArgs), _VP, _VP]),
+    "azp_pair_forces_expanded_yukawa": (C.c_int, [C.POINTER(PairArgs), _VP, _VP]),
+    "azp_pair_forces_colloid": (C.c_int, [C.POINTER(PairArgs), _VP, _VP]),
+    "azp_pair_forces_dpd_conservative": (C.c_int, [C.POINTER(PairArgs), _VP, _VP]),
+    "azp_dpd_forces_general_weight": (C.c_int, [C.POINTER(DPDArgs), _VP, _VP]),
+    "azp_aniso_forces_two_patch_morse": (C.c_int, [C.POINTER(AnisoArgs), _VP, _VP]),
+    "azp_bond_forces_double_well": (C.c_int, [C.POINTER(BondArgs), _VP, _VP, _VP]),
+    "azp_bond_forces_quartic": (C.c_int, [C.POINTER(BondArgs), _VP, _VP, _VP]),
+    "azp_nlist_cell_assign": (C.c_int, [C.POINTER(NlistArgs), _VP]),
+    "azp_nlist_cell_bounds": (C.c_int, [C.POINTER(NlistArgs), _VP]),
+    "azp_nlist_count": (C.c_int, [C.POINTER(NlistArgs), _VP]),
+    "azp_nlist_fill": (C.c_int, [C.POINTER(NlistArgs), _VP]),
+    "azp_version": (C.c_int, []),
+    "azp_status_string": (C.c_char_p, [C.c_int]),
+    "azp_last_launch": (None, [C.POINTER(C.c_uint32)] * 4),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libazp.so; raise (never fall back) if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AzpError(
+                "libazp.so not found at %s: build it with `make -C %s` (or __graft_entry__.build()); "
+                "there is no CPU fallback" % (LIB_PATH, CSRC)
+            )
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what="libazp call"):
+    if rc != 0:
+        msg = lib().azp_status_string(rc).decode()
+        raise AzpError("%s failed: status %d (%s)" % (what, rc, msg))
+
+
+def make_box(L, tilt=(0.0, 0.0, 0.0), periodic=(1, 1, 1)):
+    b = Box()
+    try:
+        L = (float(L),) * 3
+    except TypeError:
+        pass
+    for k in range(3):
+        b.L[k] = float(L[k])
+        b.tilt[k] = float(tilt[k])
+        b.periodic[k] = int(periodic[k])
+    return b
+
+
+def last_launch():
+    vals = [C.c_uint32(0) for _ in range(4)]
+    lib().azp_last_launch(*[C.byref(v) for v in vals])
+    return dict(block_size=vals[0].value, threads_per_particle=vals[1].value, grid=vals[2].value,
+                lds_bytes=vals[3].value)

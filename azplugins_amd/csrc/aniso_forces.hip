@@ -1,0 +1,286 @@
+// aniso_forces.hip -- anisotropic pair force + torque for the two-patch Morse
+// potential. Replaces HOOMD's
+// gpu_compute_pair_aniso_forces<AnisoPairEvaluatorTwoPatchMorse>, requested by
+// the reference at src/AnisoPotentialPairGPUKernel.cu.inc:21-25; per-pair
+// arithmetic restated from src/AnisoPairEvaluatorTwoPatchMorse.h:127-216.
+//
+// Lane mapping as pair_kernel.hpp. Per neighbor: position (32 B) and
+// quaternion (32 B) gathers; the patch director n = rotate(q, x^) of particle i
+// is computed once per particle, that of j once per pair. Outputs: force
+// (fx, fy, fz, e) and torque (tx, ty, tz, 0), both N x 4.
+#include "pair_kernel.hpp"
+
+namespace azp
+{
+struct TPMCoeff
+    {
+    double rcutsq, M_d, M_rinv, r_eq, omega, alpha, U_shift; // U_shift = U_Morse(r_cut) when mode == shift
+    int repulsion, _pad;
+    };
+
+struct AnisoKArgs
+    {
+    PairKArgs p;
+    const double* orientation;
+    double* torque;
+    };
+
+__device__ __forceinline__ TPMCoeff tpm_prepare(const azp_tpm_params& p, double rcutsq, bool energy_shift)
+    {
+    TPMCoeff c;
+    c.rcutsq = rcutsq;
+    c.M_d = p.M_d;
+    c.M_rinv = p.M_rinv;
+    c.r_eq = p.r_eq;
+    c.omega = p.omega;
+    c.alpha = p.alpha;
+    c.repulsion = p.repulsion ? 1 : 0;
+    c._pad = 0;
+    c.U_shift = 0.0;
+    if (energy_shift)
+        {
+        const double rcut = sqrt(rcutsq);
+        const double ex = exp(-(rcut - p.r_eq) * p.M_rinv);
+        const double om = 1.0 - ex;
+        c.U_shift = p.M_d * (om * om - 1.0);
+        }
+    return c;
+    }
+
+// rotate(q, (1,0,0)) with q = (s, u): (s^2 - |u|^2) x^ + 2 s (u x x^) + 2 u_x u
+__device__ __forceinline__ double3 patch_director(const double4& q)
+    {
+    const double s = q.x, ux = q.y, uy = q.z, uz = q.w;
+    const double c = s * s - (ux * ux + uy * uy + uz * uz);
+    return make_double3(c + 2.0 * ux * ux, 2.0 * s * uz + 2.0 * ux * uy, -2.0 * s * uy + 2.0 * ux * uz);
+    }
+__device__ __forceinline__ double3 cross3(const double3& a, const double3& b)
+    {
+    return make_double3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+    }
+
+template<int TPP, bool VIRIAL, bool SINGLE, bool WRAP>
+__device__ __forceinline__ void aniso_loop(const AnisoKArgs& a, const TPMCoeff* __restrict__ s_coeff,
+                                           const TPMCoeff& c0, uint32_t sub, uint32_t n, uint64_t head, double3 pi,
+                                           double3 n_i, int typei, double (&f)[3], double (&t)[3], double& pe,
+                                           double (&v)[6])
+    {
+    const uint32_t* __restrict__ row = a.p.nlist + head;
+    uint32_t k = sub;
+    uint32_t j = (k < n) ? row[k] : 0u;
+    while (k < n)
+        {
+        const uint32_t kn = k + TPP;
+        const uint32_t jn = (kn < n) ? row[kn] : 0u;
+        const double4 pj = load_scalar4(a.p.pos, j);
+        double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        if (WRAP)
+            min_image(a.p.box, dx, dy, dz);
+        const double rsq = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
+        TPMCoeff c;
+        if (SINGLE)
+            c = c0;
+        else
+            c = s_coeff[(uint32_t)typei * a.p.ntypes + (uint32_t)type_from_w(pj.w)];
+        if (!(rsq > c.rcutsq)) // reference returns early on rsq > rcutsq (:135-136)
+            {
+            const double4 qj = load_scalar4(a.orientation, j);
+            const double3 n_j = patch_director(qj);
+            const double rinv = 1.0 / sqrt(rsq);
+            const double r = 1.0 / rinv;
+            const double3 u = make_double3(dx * rinv, dy * rinv, dz * rinv);
+
+            double UMorse = -c.M_d;
+            double dUMorse_dr = 0.0;
+            if (r > c.r_eq || c.repulsion)
+                {
+                const double Morse_exp = exp(-(r - c.r_eq) * c.M_rinv);
+                const double one_minus_exp = 1.0 - Morse_exp;
+                UMorse = c.M_d * (one_minus_exp * one_minus_exp - 1.0);
+                dUMorse_dr = 2.0 * c.M_d * c.M_rinv * Morse_exp * one_minus_exp;
+                }
+            const double gamma_i = u.x * n_i.x + u.y * n_i.y + u.z * n_i.z;
+            const double gamma_i_exp = exp(-c.omega * (gamma_i * gamma_i - c.alpha));
+            const double Omega_i = 1.0 / (1.0 + gamma_i_exp);
+            const double gamma_j = u.x * n_j.x + u.y * n_j.y + u.z * n_j.z;
+            const double gamma_j_exp = exp(-c.omega * (gamma_j * gamma_j - c.alpha));
+            const double Omega_j = 1.0 / (1.0 + gamma_j_exp);
+
+            const double OO = Omega_i * Omega_j;
+            const double e = (UMorse - c.U_shift) * OO;
+            const double dU_dr = dUMorse_dr * OO;
+            const double dU_dgi = 2.0 * c.omega * gamma_i * gamma_i_exp * Omega_i * Omega_i * UMorse * Omega_j;
+            const double dU_dgj = 2.0 * c.omega * gamma_j * gamma_j_exp * Omega_j * Omega_j * UMorse * Omega_i;
+
+            // n_perp = cross(-u, cross(u, n))
+            const double3 rxni = cross3(u, n_i);
+            const double3 rxnj = cross3(u, n_j);
+            const double3 mu = make_double3(-u.x, -u.y, -u.z);
+            const double3 nip = cross3(mu, rxni);
+            const double3 njp = cross3(mu, rxnj);
+
+            const double Fx = -dU_dr * u.x - rinv * (dU_dgi * nip.x + dU_dgj * njp.x);
+            const double Fy = -dU_dr * u.y - rinv * (dU_dgi * nip.y + dU_dgj * njp.y);
+            const double Fz = -dU_dr * u.z - rinv * (dU_dgi * nip.z + dU_dgj * njp.z);
+            f[0] += Fx; f[1] += Fy; f[2] += Fz;
+            t[0] = __builtin_fma(dU_dgi, rxni.x, t[0]);
+            t[1] = __builtin_fma(dU_dgi, rxni.y, t[1]);
+            t[2] = __builtin_fma(dU_dgi, rxni.z, t[2]);
+            pe += e;
+            if (VIRIAL)
+                {
+                v[0] = __builtin_fma(dx, Fx, v[0]);
+                v[1] = __builtin_fma(dy, Fx, v[1]);
+                v[2] = __builtin_fma(dz, Fx, v[2]);
+                v[3] = __builtin_fma(dy, Fy, v[3]);
+                v[4] = __builtin_fma(dz, Fy, v[4]);
+                v[5] = __builtin_fma(dz, Fz, v[5]);
+                }
+            }
+        k = kn;
+        j = jn;
+        }
+    }
+
+template<int TPP, bool VIRIAL, bool SINGLE>
+__global__ void __launch_bounds__(256) aniso_forces_kernel(const AnisoKArgs a, const azp_tpm_params* __restrict__ params)
+    {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    TPMCoeff* s_coeff = reinterpret_cast<TPMCoeff*>(s_raw);
+    const bool energy_shift = (a.p.shift_mode == AZP_SHIFT_SHIFT);
+    TPMCoeff c0;
+    if (SINGLE)
+        c0 = tpm_prepare(params[0], a.p.rcutsq[0], energy_shift);
+    else
+        {
+        const uint32_t ntp = a.p.ntypes * a.p.ntypes;
+        for (uint32_t t = threadIdx.x; t < ntp; t += blockDim.x)
+            s_coeff[t] = tpm_prepare(params[t], a.p.rcutsq[t], energy_shift);
+        __syncthreads();
+        }
+
+    const uint32_t block = xcd_remap(blockIdx.x, a.p.nblocks_padded);
+    const uint32_t idx = block * (blockDim.x / TPP) + threadIdx.x / TPP;
+    const uint32_t sub = threadIdx.x % TPP;
+    const bool active = idx < a.p.N;
+
+    uint32_t n = 0;
+    uint64_t head = 0;
+    double3 pi = make_double3(0.0, 0.0, 0.0), n_i = make_double3(1.0, 0.0, 0.0);
+    int typei = 0;
+    if (active)
+        {
+        n = a.p.n_neigh[idx];
+        head = a.p.head_list[idx];
+        const double4 p = load_scalar4(a.p.pos, idx);
+        pi = make_double3(p.x, p.y, p.z);
+        typei = type_from_w(p.w);
+        n_i = patch_director(load_scalar4(a.orientation, idx));
+        }
+    double f[3] = {0.0, 0.0, 0.0}, t[3] = {0.0, 0.0, 0.0}, pe = 0.0;
+    double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+
+    bool wrap = true;
+    if (a.p.r_list_max > 0.0 && !a.p.box.triclinic)
+        {
+        const bool interior = !active || is_interior(a.p.box, pi.x, pi.y, pi.z, a.p.r_list_max);
+        wrap = !__all(interior);
+        }
+    if (wrap)
+        aniso_loop<TPP, VIRIAL, SINGLE, true>(a, s_coeff, c0, sub, n, head, pi, n_i, typei, f, t, pe, v);
+    else
+        aniso_loop<TPP, VIRIAL, SINGLE, false>(a, s_coeff, c0, sub, n, head, pi, n_i, typei, f, t, pe, v);
+
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        {
+        f[c] = group_sum<TPP>(f[c]);
+        t[c] = group_sum<TPP>(t[c]);
+        }
+    pe = group_sum<TPP>(pe);
+    if (VIRIAL)
+        {
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+            v[c] = group_sum<TPP>(v[c]);
+        }
+    if (active && sub == 0)
+        {
+        store_scalar4(a.p.force, idx, f[0], f[1], f[2], 0.5 * pe);
+        store_scalar4(a.torque, idx, t[0], t[1], t[2], 0.0);
+        if (VIRIAL)
+            {
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                a.p.virial[(uint64_t)c * a.p.virial_pitch + idx] = 0.5 * v[c];
+            }
+        }
+    }
+
+template<int TPP, bool VIRIAL, bool SINGLE>
+static int launch_aniso_instance(const azp_aniso_args& args, AnisoKArgs k, const azp_tpm_params* d_params, uint32_t bs,
+                                 hipStream_t stream)
+    {
+    const uint32_t groups = bs / TPP;
+    uint32_t nblocks = (args.pair.N + groups - 1) / groups;
+    nblocks = (nblocks + 7u) & ~7u;
+    k.p.nblocks_padded = nblocks;
+    size_t lds = SINGLE ? 0 : sizeof(TPMCoeff) * (size_t)args.pair.ntypes * args.pair.ntypes;
+    if (lds > 160 * 1024)
+        return AZP_ERROR_TOO_MANY_TYPES;
+    auto kern = aniso_forces_kernel<TPP, VIRIAL, SINGLE>;
+    if (lds > 64 * 1024)
+        {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return (int)e;
+        }
+    LaunchInfo& li = last_launch();
+    li.block_size = bs; li.tpp = TPP; li.grid = nblocks; li.lds_bytes = (uint32_t)lds;
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(bs), lds, stream, k, d_params);
+    return (int)hipGetLastError();
+    }
+
+template<bool VIRIAL, bool SINGLE>
+static int launch_aniso_tpp(const azp_aniso_args& args, const AnisoKArgs& k, const azp_tpm_params* d_params,
+                            uint32_t tpp, uint32_t bs, hipStream_t stream)
+    {
+    switch (tpp)
+        {
+    case 1: return launch_aniso_instance<1, VIRIAL, SINGLE>(args, k, d_params, bs, stream);
+    case 2: return launch_aniso_instance<2, VIRIAL, SINGLE>(args, k, d_params, bs, stream);
+    case 4: return launch_aniso_instance<4, VIRIAL, SINGLE>(args, k, d_params, bs, stream);
+    case 8: return launch_aniso_instance<8, VIRIAL, SINGLE>(args, k, d_params, bs, stream);
+    case 16: return launch_aniso_instance<16, VIRIAL, SINGLE>(args, k, d_params, bs, stream);
+    case 32: return launch_aniso_instance<32, VIRIAL, SINGLE>(args, k, d_params, bs, stream);
+    default: return AZP_ERROR_INVALID_ARGUMENT;
+        }
+    }
+} // namespace azp
+
+extern "C" int azp_aniso_forces_two_patch_morse(const azp_aniso_args* args, const azp_tpm_params* d_params,
+                                                void* stream)
+    {
+    using namespace azp;
+    if (!args)
+        return AZP_ERROR_INVALID_ARGUMENT;
+    const int bad = validate_pair_args(&args->pair, d_params);
+    if (bad < 0) return bad;
+    if (bad > 0) return AZP_SUCCESS;
+    if (!args->d_orientation || !args->d_torque || args->pair.shift_mode == AZP_SHIFT_XPLOR)
+        return AZP_ERROR_INVALID_ARGUMENT; // HOOMD aniso pairs accept "none" / "shift"
+    AnisoKArgs k;
+    k.p = make_pair_kargs(args->pair);
+    k.orientation = args->d_orientation;
+    k.torque = args->d_torque;
+    const uint32_t tpp = choose_tpp(args->pair);
+    const uint32_t bs = args->pair.block_size ? args->pair.block_size : 256u;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool single = (args->pair.ntypes == 1);
+    if (args->pair.compute_virial)
+        return single ? launch_aniso_tpp<true, true>(*args, k, d_params, tpp, bs, s)
+                      : launch_aniso_tpp<true, false>(*args, k, d_params, tpp, bs, s);
+    return single ? launch_aniso_tpp<false, true>(*args, k, d_params, tpp, bs, s)
+                  : launch_aniso_tpp<false, false>(*args, k, d_params, tpp, bs, s);
+    }

@@ -1,0 +1,470 @@
+// evaluators.hpp -- device restatement of the azplugins per-pair / per-bond
+// arithmetic, written for the gfx950 kernels in this directory.
+//
+// Each isotropic pair evaluator E provides
+//   E::Params                     raw per-type-pair struct (include/azp.h,
+//                                 byte-compatible with the reference param_type)
+//   E::Coeff                      everything that is constant per type pair,
+//                                 derived ONCE per kernel (not per pair as in
+//                                 the reference's evaluator constructors)
+//   E::prepare(params, rcutsq, energy_shift) -> Coeff
+//   E::eval(coeff, rsq, force_divr, pair_eng) -> bool evaluated
+// Coeff tables live in LDS when ntypes > 1 and in registers when ntypes == 1.
+#pragma once
+
+#include "azp_device.hpp"
+
+namespace azp
+{
+// ---------------------------------------------------------------------------
+// PerturbedLennardJones -- src/PairEvaluatorPerturbedLennardJones.h:96-155
+// Branch-free: the WCA / tail / cutoff decisions become selects so a wave
+// never diverges inside the neighbor loop.
+// ---------------------------------------------------------------------------
+struct EvalPLJ
+    {
+    typedef azp_plj_params Params;
+    struct Coeff
+        {
+        double rcutsq;    // effective cutoff^2; -1 when lj1 == 0 (":123 lj1 != 0" guard)
+        double c12, c6;   // 12 lj1, 6 lj2
+        double lj1, lj2;
+        double lam;       // attraction_scale_factor
+        double rwcasq;
+        double wca_add;   // wca_shift - e_cut      (energy offset inside the WCA core)
+        double tail_add;  // -e_cut                 (energy offset in the scaled tail)
+        };
+    static __device__ __forceinline__ Coeff prepare(const Params& p, double rcutsq, bool energy_shift)
+        {
+        Coeff c;
+        const double lj1 = p.epsilon_x_4 * p.sigma_6 * p.sigma_6;
+        const double lj2 = p.epsilon_x_4 * p.sigma_6;
+        const double lam = p.attraction_scale_factor;
+        const double wca_shift = p.epsilon_x_4 * (1.0 - lam) / 4.0;
+        double e_cut = 0.0;
+        if (energy_shift)
+            {
+            const double rcut2inv = 1.0 / rcutsq;
+            const double rcut6inv = rcut2inv * rcut2inv * rcut2inv;
+            e_cut = rcut6inv * (lj1 * rcut6inv - lj2);
+            if (rcutsq < p.rwcasq)
+                e_cut += wca_shift;
+            else
+                e_cut *= lam;
+            }
+        c.rcutsq = (lj1 != 0.0) ? rcutsq : -1.0;
+        c.c12 = 12.0 * lj1;
+        c.c6 = 6.0 * lj2;
+        c.lj1 = lj1;
+        c.lj2 = lj2;
+        c.lam = lam;
+        c.rwcasq = p.rwcasq;
+        c.wca_add = wca_shift - e_cut;
+        c.tail_add = -e_cut;
+        return c;
+        }
+    static __device__ __forceinline__ bool eval(const Coeff& c, double rsq, double& force_divr, double& pair_eng)
+        {
+        const bool in = rsq < c.rcutsq;
+        const bool wca = rsq < c.rwcasq;
+        const double r2inv = fast_rcp(rsq);
+        const double r6inv = r2inv * r2inv * r2inv;
+        const double f = r2inv * r6inv * __builtin_fma(c.c12, r6inv, -c.c6);
+        const double e = r6inv * __builtin_fma(c.lj1, r6inv, -c.lj2);
+        const double scale = in ? (wca ? 1.0 : c.lam) : 0.0;
+        const double add = in ? (wca ? c.wca_add : c.tail_add) : 0.0;
+        force_divr = f * scale;
+        pair_eng = __builtin_fma(e, scale, add);
+        return in;
+        }
+    };
+
+// ---------------------------------------------------------------------------
+// Hertz -- src/PairEvaluatorHertz.h:93-110 (energy_shift has no effect)
+// ---------------------------------------------------------------------------
+struct EvalHertz
+    {
+    typedef azp_hertz_params Params;
+    struct Coeff
+        {
+        double rcutsq, epsilon, rcut, rcutinv;
+        };
+    static __device__ __forceinline__ Coeff prepare(const Params& p, double rcutsq, bool)
+        {
+        Coeff c;
+        c.rcutsq = (p.epsilon != 0.0) ? rcutsq : -1.0;
+        c.epsilon = p.epsilon;
+        c.rcut = sqrt(rcutsq);
+        c.rcutinv = 1.0 / c.rcut;
+        return c;
+        }
+    static __device__ __forceinline__ bool eval(const Coeff& c, double rsq, double& force_divr, double& pair_eng)
+        {
+        force_divr = 0.0;
+        pair_eng = 0.0;
+        if (rsq < c.rcutsq)
+            {
+            const double r = sqrt(rsq);
+            const double x = 1.0 - r / c.rcut;
+            const double xsqrt = sqrt(x);
+            const double ex3p2 = c.epsilon * x * xsqrt;
+            force_divr = 2.5 * ex3p2 / (r * c.rcut);
+            pair_eng = ex3p2 * x;
+            return true;
+            }
+        return false;
+        }
+    };
+
+// ---------------------------------------------------------------------------
+// ExpandedYukawa -- src/PairEvaluatorExpandedYukawa.h:92-115
+// ---------------------------------------------------------------------------
+struct EvalYukawa
+    {
+    typedef azp_yukawa_params Params;
+    struct Coeff
+        {
+        double rcutsq, epsilon, kappa, delta, e_cut;
+        };
+    static __device__ __forceinline__ Coeff prepare(const Params& p, double rcutsq, bool energy_shift)
+        {
+        Coeff c;
+        c.rcutsq = (p.epsilon != 0.0) ? rcutsq : -1.0;
+        c.epsilon = p.epsilon;
+        c.kappa = p.kappa;
+        c.delta = p.delta;
+        c.e_cut = 0.0;
+        if (energy_shift)
+            {
+            const double rcut_delta = sqrt(rcutsq) - p.delta;
+            c.e_cut = p.epsilon * exp(-p.kappa * rcut_delta) / rcut_delta;
+            }
+        return c;
+        }
+    static __device__ __forceinline__ bool eval(const Coeff& c, double rsq, double& force_divr, double& pair_eng)
+        {
+        force_divr = 0.0;
+        pair_eng = 0.0;
+        if (rsq < c.rcutsq)
+            {
+            const double r = sqrt(rsq);
+            const double r_delta = r - c.delta;
+            const double r_delta_inv = 1.0 / r_delta;
+            const double e = c.epsilon * exp(-c.kappa * r_delta) * r_delta_inv;
+            force_divr = e * (c.kappa + r_delta_inv) / r;
+            pair_eng = e - c.e_cut;
+            return true;
+            }
+        return false;
+        }
+    };
+
+// ---------------------------------------------------------------------------
+// Colloid -- src/PairEvaluatorColloid.h:101-269
+// kind is fixed per type pair: 0 solvent-solvent, 1 colloid-solvent,
+// 2 colloid-colloid (dispatch at :239-262).
+// ---------------------------------------------------------------------------
+struct EvalColloid
+    {
+    typedef azp_colloid_params Params;
+    struct Coeff
+        {
+        double rcutsq, A, ai, aj, sigma_3, sigma_6, e_cut;
+        int kind;
+        int _pad;
+        };
+
+    template<bool FORCE>
+    static __device__ __forceinline__ double solvent_solvent(const Coeff& c, double& force_divr, double rsq)
+        {
+        const double r2inv = 1.0 / rsq;
+        const double r6inv = r2inv * r2inv * r2inv;
+        const double c1 = c.A * c.sigma_6 / 36.0;
+        if (FORCE)
+            force_divr = 6.0 * c1 * r2inv * r6inv * (2.0 * c.sigma_6 * r6inv - 1.0);
+        return c1 * r6inv * (c.sigma_6 * r6inv - 1.0);
+        }
+    template<bool FORCE>
+    static __device__ __forceinline__ double colloid_solvent(const Coeff& c, double& force_divr, double rsq)
+        {
+        const double a = (c.ai > c.aj) ? c.ai : c.aj;
+        const double asq = a * a;
+        const double asq_minus_rsq = asq - rsq;
+        const double rsqsq = rsq * rsq;
+        const double amr3 = asq_minus_rsq * asq_minus_rsq * asq_minus_rsq;
+        const double amr6 = amr3 * amr3;
+        const double fR = c.sigma_3 * c.A * a * asq / amr3;
+        if (FORCE)
+            {
+            force_divr = (4.0 / 15.0) * fR
+                         * (2.0 * (asq + rsq) * (asq * (5.0 * asq + 22.0 * rsq) + 5.0 * rsqsq) * c.sigma_6 / amr6 - 5.0)
+                         / asq_minus_rsq;
+            }
+        return (2.0 / 9.0) * fR
+               * (1.0 - (asq * (asq * (asq / 3.0 + 3.0 * rsq) + 4.2 * rsqsq) + rsq * rsqsq) * c.sigma_6 / amr6);
+        }
+    template<bool FORCE>
+    static __device__ __forceinline__ double colloid_colloid(const Coeff& c, double& force_divr, double rsq)
+        {
+        const double r = sqrt(rsq);
+        const double k0 = c.ai * c.aj;
+        const double k1 = c.ai + c.aj;
+        const double k2 = c.ai - c.aj;
+        const double k3 = k1 + r;
+        const double k4 = k1 - r;
+        const double k5 = k2 + r;
+        const double k6 = k2 - r;
+        const double k7 = 1.0 / (k3 * k4);
+        const double k8 = 1.0 / (k5 * k6);
+
+        const double k3inv = 1.0 / k3;
+        double g0 = k3inv * k3inv; g0 *= g0 * g0; g0 *= k3inv;
+        const double k4inv = 1.0 / k4;
+        double g1 = k4inv * k4inv; g1 *= g1 * g1; g1 *= k4inv;
+        const double k5inv = 1.0 / k5;
+        double g2 = k5inv * k5inv; g2 *= g2 * g2; g2 *= k5inv;
+        const double k6inv = 1.0 / k6;
+        double g3 = k6inv * k6inv; g3 *= g3 * g3; g3 *= k6inv;
+
+        const double h0 = ((k3 + 5.0 * k1) * k3 + 30.0 * k0) * g0;
+        const double h1 = ((k4 + 5.0 * k1) * k4 + 30.0 * k0) * g1;
+        const double h2 = ((k5 + 5.0 * k2) * k5 - 30.0 * k0) * g2;
+        const double h3 = ((k6 + 5.0 * k2) * k6 - 30.0 * k0) * g3;
+
+        g0 *= 42.0 * k0 * k3inv + 6.0 * k1 + k3;
+        g1 *= 42.0 * k0 * k4inv + 6.0 * k1 + k4;
+        g2 *= -42.0 * k0 * k5inv + 6.0 * k2 + k5;
+        g3 *= -42.0 * k0 * k6inv + 6.0 * k2 + k6;
+
+        const double rinv = 1.0 / r;
+        const double fR = c.A * c.sigma_6 * rinv / 37800.0;
+        double pair_eng = fR * (h0 - h1 - h2 + h3);
+        if (FORCE)
+            {
+            const double dUR = pair_eng * rinv + 5.0 * fR * (g0 + g1 - g2 - g3);
+            const double dUA = -c.A / 3.0 * r * ((2.0 * k0 * k7 + 1.0) * k7 + (2.0 * k0 * k8 - 1.0) * k8);
+            force_divr = (dUR + dUA) * rinv;
+            }
+        pair_eng += c.A / 6.0 * (2.0 * k0 * (k7 + k8) - log(k8 / k7));
+        return pair_eng;
+        }
+
+    static __device__ __forceinline__ Coeff prepare(const Params& p, double rcutsq, bool energy_shift)
+        {
+        Coeff c;
+        c.rcutsq = (p.A != 0.0) ? rcutsq : -1.0;
+        c.A = p.A;
+        c.ai = p.a_1;
+        c.aj = p.a_2;
+        c.sigma_3 = p.sigma_3;
+        c.sigma_6 = p.sigma_3 * p.sigma_3;
+        c.kind = (p.a_1 == 0.0 && p.a_2 == 0.0) ? 0 : ((p.a_1 != 0.0 && p.a_2 != 0.0) ? 2 : 1);
+        c._pad = 0;
+        c.e_cut = 0.0;
+        if (energy_shift && p.A != 0.0)
+            {
+            double dummy;
+            if (c.kind == 0)
+                c.e_cut = solvent_solvent<false>(c, dummy, rcutsq);
+            else if (c.kind == 2)
+                c.e_cut = colloid_colloid<false>(c, dummy, rcutsq);
+            else
+                c.e_cut = colloid_solvent<false>(c, dummy, rcutsq);
+            }
+        return c;
+        }
+    static __device__ __forceinline__ bool eval(const Coeff& c, double rsq, double& force_divr, double& pair_eng)
+        {
+        force_divr = 0.0;
+        pair_eng = 0.0;
+        if (rsq < c.rcutsq)
+            {
+            double e;
+            if (c.kind == 0)
+                e = solvent_solvent<true>(c, force_divr, rsq);
+            else if (c.kind == 2)
+                e = colloid_colloid<true>(c, force_divr, rsq);
+            else
+                e = colloid_solvent<true>(c, force_divr, rsq);
+            pair_eng = e - c.e_cut;
+            return true;
+            }
+        return false;
+        }
+    };
+
+// ---------------------------------------------------------------------------
+// DPD conservative part -- src/DPDPairEvaluatorGeneralWeight.h:165-183
+// (no A != 0 guard; energy_shift ignored). Also the base of the thermostat.
+// ---------------------------------------------------------------------------
+struct EvalDPDConservative
+    {
+    typedef azp_dpd_params Params;
+    struct Coeff
+        {
+        double rcutsq, A, gamma, half_s, rcut, rcutinv;
+        };
+    static __device__ __forceinline__ Coeff prepare(const Params& p, double rcutsq, bool)
+        {
+        Coeff c;
+        c.rcutsq = rcutsq;
+        c.A = p.A;
+        c.gamma = p.gamma;
+        c.half_s = 0.5 * p.s;
+        c.rcutinv = 1.0 / sqrt(rcutsq);
+        c.rcut = 1.0 / c.rcutinv;
+        return c;
+        }
+    static __device__ __forceinline__ bool eval(const Coeff& c, double rsq, double& force_divr, double& pair_eng)
+        {
+        force_divr = 0.0;
+        pair_eng = 0.0;
+        if (rsq < c.rcutsq)
+            {
+            const double rinv = 1.0 / sqrt(rsq);
+            const double r = 1.0 / rinv;
+            force_divr = c.A * (rinv - c.rcutinv);
+            pair_eng = c.A * (c.rcut - r) - 0.5 * c.A * c.rcutinv * (c.rcutsq - rsq);
+            return true;
+            }
+        return false;
+        }
+    };
+
+// ---------------------------------------------------------------------------
+// XPLOR smoothing applied around any isotropic evaluator (HOOMD PotentialPair
+// restated; not pinned by a reference test).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void apply_xplor(double rsq, double ronsq, double rcutsq, double& force_divr,
+                                            double& pair_eng)
+    {
+    if (rsq >= ronsq && rsq < rcutsq)
+        {
+        const double old_pair_eng = pair_eng;
+        const double old_force_divr = force_divr;
+        const double d = rcutsq - ronsq;
+        const double xplor_denom_inv = 1.0 / (d * d * d);
+        const double rsq_minus_r_cut_sq = rsq - rcutsq;
+        const double s = rsq_minus_r_cut_sq * rsq_minus_r_cut_sq * (rcutsq + 2.0 * rsq - 3.0 * ronsq) * xplor_denom_inv;
+        const double ds_dr_divr = 12.0 * (rsq - ronsq) * rsq_minus_r_cut_sq * xplor_denom_inv;
+        pair_eng = old_pair_eng * s;
+        force_divr = s * old_force_divr - ds_dr_divr * old_pair_eng;
+        }
+    }
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 (Random123 algorithm) and the HOOMD-style stream the DPD
+// thermostat draws from: key = {id<<24 | ts[39:32]<<16 | seed, ts[31:0]},
+// counter = {0, min tag, max tag, 0}; alpha = uniform(-1, 1].
+// Call site restated: src/DPDPairEvaluatorGeneralWeight.h:213-233.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0,
+                                              uint32_t k1)
+    {
+#pragma unroll
+    for (int round = 0; round < 10; ++round)
+        {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+        }
+    }
+
+__device__ __forceinline__ double dpd_alpha(uint16_t seed, uint32_t tag_i, uint32_t tag_j, uint64_t timestep)
+    {
+    const uint32_t oi = tag_i > tag_j ? tag_j : tag_i;
+    const uint32_t oj = tag_i > tag_j ? tag_i : tag_j;
+    const uint64_t ts = (uint64_t)(uint32_t)timestep; // reference passes unsigned int (:130-137)
+    const uint32_t k0 = (200u << 24) | ((uint32_t)((ts >> 32) & 0xffu) << 16) | (uint32_t)seed;
+    const uint32_t k1 = (uint32_t)(ts & 0xffffffffu);
+    uint32_t c0 = 0, c1 = oi, c2 = oj, c3 = 0;
+    philox4x32_10(c0, c1, c2, c3, k0, k1);
+    const uint64_t u = ((uint64_t)c0 << 32) | (uint64_t)c1;
+    const double u01 = (double)(u >> 11) * (1.0 / 9007199254740992.0) + (0.5 / 9007199254740992.0);
+    return -1.0 + 2.0 * u01;
+    }
+
+// ---------------------------------------------------------------------------
+// Bond evaluators
+// ---------------------------------------------------------------------------
+struct EvalDoubleWell // src/BondEvaluatorDoubleWell.h:96-113
+    {
+    typedef azp_dw_params Params;
+    static __device__ __forceinline__ bool eval(const Params& p, double rsq, double& force_divr, double& bond_eng)
+        {
+        bond_eng = 0.0;
+        force_divr = 0.0;
+        if (p.r_diff == 0.0)
+            return false;
+        const double r = sqrt(rsq);
+        const double x = (p.r_1 - r) / p.r_diff;
+        const double x2 = x * x;
+        const double y = 1.0 - x2;
+        const double y2 = y * y;
+        bond_eng = p.U_1 * y2 + p.U_tilt * (1.0 - x - y2);
+        force_divr = (4.0 * x * y * (p.U_tilt - p.U_1) - p.U_tilt) / (p.r_diff * r);
+        return true;
+        }
+    };
+
+struct EvalQuartic // src/BondEvaluatorQuartic.h:113-200
+    {
+    typedef azp_quartic_params Params;
+    static __device__ __forceinline__ bool eval(const Params& p, double rsq, double& force_divr, double& bond_eng)
+        {
+        const double lj1 = p.epsilon_x_4 * p.sigma_6 * p.sigma_6;
+        const double lj2 = p.epsilon_x_4 * p.sigma_6;
+        const double k = p.k, r_0 = p.r_0, b_1 = p.b_1, b_2 = p.b_2, U_0 = p.U_0, delta = p.delta;
+        double f = 0.0, e = 0.0;
+        bond_eng = 0.0;
+        force_divr = 0.0;
+        if (r_0 == 0.0)
+            return false;
+        double r_red = 1.0;
+        if (delta == 0.0)
+            {
+            const double r2inv = 1.0 / rsq;
+            const double r6inv = r2inv * r2inv * r2inv;
+            const double sigma6inv = lj2 / lj1;
+            if (lj1 != 0.0 && r6inv > sigma6inv / 2.0)
+                {
+                const double epsilon = lj2 * lj2 / 4.0 / lj1;
+                f += r2inv * r6inv * (12.0 * lj1 * r6inv - 6.0 * lj2);
+                e += r6inv * (lj1 * r6inv - lj2) + epsilon;
+                }
+            if (rsq < r_0 * r_0)
+                r_red = sqrt(rsq) - r_0;
+            }
+        else
+            {
+            const double r = sqrt(rsq) - delta;
+            const double r2inv = 1.0 / r / r;
+            const double r6inv = r2inv * r2inv * r2inv;
+            const double sigma6inv = lj2 / lj1;
+            if (lj1 != 0.0 && r6inv > sigma6inv / 2.0)
+                {
+                f += r6inv * (12.0 * lj1 * r6inv - 6.0 * lj2) / r / (r + delta);
+                e += r6inv * (lj1 * r6inv - lj2) + p.epsilon_x_4 / 4.0;
+                }
+            if (r < r_0)
+                r_red = r - r_0;
+            }
+        if (r_red < 0.0)
+            {
+            f += -1.0 * k * r_red * (4.0 * r_red * r_red - 3.0 * (b_1 + b_2) * r_red + 2.0 * b_1 * b_2)
+                 / (r_red + r_0 + delta);
+            e += k * (r_red - b_1) * (r_red - b_2) * r_red * r_red + U_0;
+            }
+        else
+            e += U_0;
+        force_divr = f;
+        bond_eng = e;
+        return true;
+        }
+    };
+
+} // namespace azp

@@ -1,0 +1,128 @@
+"""Neighbor lists: the data ``hoomd.md.nlist.Cell(buffer=...)`` hands to the pair
+potentials in every reference test (e.g. src/pytest/test_pair.py:337), built on
+the GPU by libazp's ``azp_nlist_*`` kernels.
+
+torch is used for the sort / scan steps between the kernels and to hold the
+buffers; the binning, counting and filling are libazp kernels.
+"""
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class NeighborList:
+    """Base: holds the device arrays in HOOMD's layout."""
+
+    def __init__(self, buffer, exclusions=("bond",)):
+        self.buffer = float(buffer)
+        self.exclusions = tuple(exclusions)
+        self._consumers = []
+        self.n_neigh = None
+        self.head_list = None
+        self.nlist = None
+        self.size = 0
+        self._built_generation = None
+        self.num_builds = 0
+
+    # -- consumers (pair potentials) register their r_cut matrices ---------
+    def _add_consumer(self, force):
+        if force not in self._consumers:
+            self._consumers.append(force)
+
+    def _r_cut_matrix(self, ntypes):
+        rc = np.zeros((ntypes, ntypes))
+        for f in self._consumers:
+            rc = np.maximum(rc, f._r_cut_matrix())
+        return rc
+
+    @property
+    def r_list_max(self):
+        """Upper bound on the separation of any listed pair between rebuilds."""
+        return self._r_cut_max + 2.0 * self.buffer
+
+
+class Cell(NeighborList):
+    """Cell-list neighbor list (full storage, as HOOMD's GPU pair kernels use)."""
+
+    def compute(self, state, force=False):
+        if not force and self._built_generation == state.position_generation and self.nlist is not None:
+            return
+        self._build(state)
+        self._built_generation = state.position_generation
+
+    def _build(self, state):
+        import torch
+
+        l = _lib.lib()
+        dev = state.device
+        ntypes = len(state.types)
+        rc = self._r_cut_matrix(ntypes)
+        self._r_cut_max = float(rc.max())
+        rl = np.where(rc > 0.0, rc + self.buffer, 0.0)
+        rl_max = float(rl.max())
+        if rl_max <= 0.0:
+            raise _lib.AzpError("neighbor list has no consumer with r_cut > 0")
+        box = state.box
+        L = box.L
+        for k in range(3):
+            if box.periodic[k] and L[k] < 2.0 * rl_max:
+                raise _lib.AzpError("box dimension %d (%g) is smaller than 2 (r_cut + buffer) = %g" % (k, L[k], 2 * rl_max))
+        n_total = state.n_max
+        N = state.N
+        a = _lib.NlistArgs()
+        a.N = N
+        a.n_total = n_total
+        a.d_pos = state.pos.data_ptr()
+        a.box = box.to_c()
+        # grid over the periodic box; a triclinic box is binned in its bounding
+        # orthorhombic frame only when untilted, so require orthorhombic here
+        if box.is_triclinic:
+            raise _lib.AzpError("Cell neighbor list: triclinic boxes are not supported yet")
+        for k in range(3):
+            dim = max(int(np.floor(L[k] / rl_max)), 1)
+            a.grid.dim[k] = dim
+            a.grid.width[k] = L[k] / dim
+            a.grid.lo[k] = -0.5 * L[k]
+            a.grid.periodic[k] = 1 if box.periodic[k] else 0
+        ncell = int(a.grid.dim[0]) * int(a.grid.dim[1]) * int(a.grid.dim[2])
+        a.ntypes = ntypes
+        rlistsq = torch.from_numpy(np.ascontiguousarray((rl * rl).reshape(-1))).to(dev)
+        a.d_rlistsq = rlistsq.data_ptr()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+
+        cell_of = torch.empty(n_total, dtype=torch.int32, device=dev)
+        a.d_cell_of = cell_of.data_ptr()
+        _lib.check(l.azp_nlist_cell_assign(C.byref(a), stream), "azp_nlist_cell_assign")
+        cell_sorted, order = torch.sort(cell_of, stable=True)
+        order = order.to(torch.int32)
+        cell_start = torch.empty(ncell + 1, dtype=torch.int32, device=dev)
+        a.d_cell_sorted = cell_sorted.data_ptr()
+        a.d_order = order.data_ptr()
+        a.d_cell_start = cell_start.data_ptr()
+        _lib.check(l.azp_nlist_cell_bounds(C.byref(a), stream), "azp_nlist_cell_bounds")
+
+        keep = []
+        if "bond" in self.exclusions and state.bond_group.shape[0]:
+            n_excl, excl, pitch = state.exclusion_table()
+            a.d_n_excl = n_excl.data_ptr()
+            a.d_excl = excl.data_ptr()
+            a.excl_pitch = pitch
+            keep += [n_excl, excl]
+
+        n_neigh = torch.empty(N, dtype=torch.int32, device=dev)
+        a.d_n_neigh = n_neigh.data_ptr()
+        _lib.check(l.azp_nlist_count(C.byref(a), stream), "azp_nlist_count")
+        incl = torch.cumsum(n_neigh.to(torch.int64), 0)
+        head = incl - n_neigh.to(torch.int64)
+        size = int(incl[-1].item()) if N else 0
+        nlist = torch.empty(max(size, 1), dtype=torch.int32, device=dev)
+        a.d_head_list = head.data_ptr()
+        a.d_nlist = nlist.data_ptr()
+        _lib.check(l.azp_nlist_fill(C.byref(a), stream), "azp_nlist_fill")
+
+        self.n_neigh, self.head_list, self.nlist, self.size = n_neigh, head, nlist, size
+        self.num_builds += 1
+        self._keep = (rlistsq, cell_of, cell_sorted, order, cell_start, keep)

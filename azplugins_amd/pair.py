@@ -1,0 +1,320 @@
+"""Pair potentials: drop-in mirror of ``hoomd.azplugins.pair`` (reference
+``src/pair.py``) driving libazp's gfx950 kernels through the C ABI.
+
+Class names, constructor arguments, parameter keys, accepted ``mode`` values and
+the parameter round trip follow the reference (file:line in each class). What
+the reference delegates to HOOMD's ``hoomd.md.pair.Pair`` -- ``r_cut`` / ``r_on``
+type parameters, ``mode``, attaching -- is restated here in reduced form.
+"""
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .force import Force, ScalarTypeParameter, TypeParameter
+
+_SHIFT = {"none": 0, "shift": 1, "xplor": 2}
+
+
+class Pair(Force):
+    """Reduced ``hoomd.md.pair.Pair``: neighbor list, per-type-pair ``params``,
+    ``r_cut``, ``r_on`` and ``mode``."""
+
+    _cpp_class_name = None          # name the reference registers in _azplugins
+    _entry = None                   # libazp entry point
+    _schema = {}
+    _param_doubles = 4              # size of the raw param struct in doubles
+    _accepted_modes = ("none", "shift", "xplor")
+
+    def __init__(self, nlist, default_r_cut=None, default_r_on=0.0, mode="none"):
+        super().__init__()
+        if mode not in self._accepted_modes:
+            raise ValueError("mode must be one of %s, got %r" % (self._accepted_modes, mode))
+        self.nlist = nlist
+        self._mode = mode
+        self.params = TypeParameter("params", self._schema, 2, self._mark_dirty, self._readback)
+        self.r_cut = ScalarTypeParameter("r_cut", default_r_cut, self._mark_dirty)
+        self.r_on = ScalarTypeParameter("r_on", default_r_on, self._mark_dirty)
+        self.threads_per_particle = 0   # 0 = library heuristic (HOOMD autotunes this)
+        self.block_size = 0
+        self._tables = None
+        nlist._add_consumer(self)
+
+    # -- mode ----------------------------------------------------------------
+    @property
+    def mode(self):
+        return self._mode
+
+    @mode.setter
+    def mode(self, m):
+        if m not in self._accepted_modes:
+            raise ValueError("mode must be one of %s, got %r" % (self._accepted_modes, m))
+        self._mode = m
+        self._mark_dirty()
+
+    def _mark_dirty(self):
+        self._tables = None
+        self._computed_generation = None
+
+    # -- raw parameter structs (host side of the C ABI) ------------------------
+    def _pack(self, d):
+        raise NotImplementedError
+
+    def _unpack(self, raw):
+        raise NotImplementedError
+
+    def _readback(self, key):
+        """After attaching, ``params[...]`` returns what the C side holds
+        (HOOMD: getParams -> asDict), as the reference tests check
+        (src/pytest/test_pair.py:349)."""
+        if not self._attached or key not in self.params._data:
+            return None
+        return self._unpack(self._pack(self.params._data[key]))
+
+    def _types(self):
+        return self._state.types if self._attached else None
+
+    def _r_cut_matrix(self):
+        self._require()
+        types = self._state.types
+        T = len(types)
+        rc = np.zeros((T, T))
+        for i, a in enumerate(types):
+            for j, b in enumerate(types):
+                rc[i, j] = self.r_cut[(a, b)]
+        return rc
+
+    def _attach(self, sim):
+        super()._attach(sim)
+        self._tables = None
+
+    def _build_tables(self):
+        import torch
+
+        types = self._state.types
+        T = len(types)
+        raw = np.zeros((T * T, self._param_doubles))
+        rc = np.zeros(T * T)
+        ro = np.zeros(T * T)
+        for i, a in enumerate(types):
+            for j, b in enumerate(types):
+                d = self.params.get_raw((a, b))
+                if d is None:
+                    raise _lib.AzpError("%s.params[(%r, %r)] is not set" % (type(self).__name__, a, b))
+                raw[i * T + j] = self._pack(d)
+                rc[i * T + j] = self.r_cut[(a, b)] ** 2
+                ro[i * T + j] = self.r_on[(a, b)] ** 2
+        dev = self._state.device
+        self._tables = dict(
+            params=torch.from_numpy(raw).to(dev), rcutsq=torch.from_numpy(rc).to(dev), ronsq=torch.from_numpy(ro).to(dev)
+        )
+
+    def _pair_args(self):
+        st = self._state
+        nl = self.nlist
+        a = _lib.PairArgs()
+        a.d_force = self._force.data_ptr()
+        a.d_virial = self._virial.data_ptr()
+        a.virial_pitch = st.N
+        a.N = st.N
+        a.n_max = st.n_max
+        a.d_pos = st.pos.data_ptr()
+        a.box = st.box.to_c()
+        a.d_n_neigh = nl.n_neigh.data_ptr()
+        a.d_nlist = nl.nlist.data_ptr()
+        a.d_head_list = nl.head_list.data_ptr()
+        a.d_rcutsq = self._tables["rcutsq"].data_ptr()
+        a.d_ronsq = self._tables["ronsq"].data_ptr()
+        a.size_nlist = nl.size
+        a.ntypes = len(st.types)
+        a.shift_mode = _SHIFT[self._mode]
+        a.compute_virial = 1 if self.compute_virial else 0
+        a.block_size = self.block_size
+        a.threads_per_particle = self.threads_per_particle
+        a.r_list_max = nl.r_list_max
+        return a
+
+    def compute(self, timestep=None):
+        import torch
+
+        self._require()
+        st = self._state
+        self.nlist.compute(st)
+        if self._tables is None:
+            self._build_tables()
+        stream = torch.cuda.current_stream(st.device).cuda_stream
+        self._launch(stream, timestep)
+        self._computed_generation = st.position_generation
+
+    def _launch(self, stream, timestep):
+        a = self._pair_args()
+        fn = getattr(_lib.lib(), self._entry)
+        _lib.check(fn(C.byref(a), self._tables["params"].data_ptr(), stream), self._entry)
+
+
+def _d(x):
+    return C.c_double(x)
+
+
+class Colloid(Pair):
+    """Colloid pair potential (reference ``src/pair.py:14-118``)."""
+
+    _cpp_class_name = "PotentialPairColloid"
+    _entry = "azp_pair_forces_colloid"
+    _schema = dict(A=float, a_1=float, a_2=float, sigma=float)
+
+    def _pack(self, d):
+        out = np.zeros(4)
+        _lib.lib().azp_colloid_params_make(d["A"], d["a_1"], d["a_2"], d["sigma"], out.ctypes.data)
+        return out
+
+    def _unpack(self, raw):
+        v = [C.c_double() for _ in range(4)]
+        _lib.lib().azp_colloid_params_unpack(raw.ctypes.data, *[C.byref(x) for x in v])
+        return dict(A=v[0].value, a_1=v[1].value, a_2=v[2].value, sigma=v[3].value)
+
+
+class ExpandedYukawa(Pair):
+    """Expanded Yukawa pair potential (reference ``src/pair.py:242-297``)."""
+
+    _cpp_class_name = "PotentialPairExpandedYukawa"
+    _entry = "azp_pair_forces_expanded_yukawa"
+    _schema = dict(epsilon=float, kappa=float, delta=float)
+
+    def _pack(self, d):
+        return np.array([d["epsilon"], d["kappa"], d["delta"], 0.0])
+
+    def _unpack(self, raw):
+        return dict(epsilon=float(raw[0]), kappa=float(raw[1]), delta=float(raw[2]))
+
+
+class Hertz(Pair):
+    """Hertz pair potential (reference ``src/pair.py:300-351``)."""
+
+    _cpp_class_name = "PotentialPairHertz"
+    _entry = "azp_pair_forces_hertz"
+    _schema = dict(epsilon=float)
+    _param_doubles = 1
+
+    def _pack(self, d):
+        return np.array([d["epsilon"]])
+
+    def _unpack(self, raw):
+        return dict(epsilon=float(raw[0]))
+
+
+class PerturbedLennardJones(Pair):
+    """Perturbed Lennard-Jones pair potential (reference ``src/pair.py:354-426``)."""
+
+    _cpp_class_name = "PotentialPairPerturbedLennardJones"
+    _entry = "azp_pair_forces_perturbed_lennard_jones"
+    _schema = dict(epsilon=float, sigma=float, attraction_scale_factor=float)
+
+    def _pack(self, d):
+        out = np.zeros(4)
+        _lib.lib().azp_plj_params_make(d["epsilon"], d["sigma"], d["attraction_scale_factor"], out.ctypes.data)
+        return out
+
+    def _unpack(self, raw):
+        v = [C.c_double() for _ in range(3)]
+        _lib.lib().azp_plj_params_unpack(raw.ctypes.data, *[C.byref(x) for x in v])
+        return dict(epsilon=v[0].value, sigma=v[1].value, attraction_scale_factor=v[2].value)
+
+
+class DPDGeneralWeight(Pair):
+    """DPD thermostat with generalized weight function (reference
+    ``src/pair.py:121-239``). ``kT`` may be a float or a callable of the
+    timestep (HOOMD ``Variant``). ``mode`` is always ``"none"``."""
+
+    _cpp_class_name = "PotentialPairDPDThermoGeneralWeight"
+    _entry = "azp_dpd_forces_general_weight"
+    _schema = dict(A=float, gamma=float, s=float)
+    _accepted_modes = ("none",)
+
+    def __init__(self, nlist, kT, default_r_cut=None):
+        super().__init__(nlist, default_r_cut=default_r_cut, default_r_on=0.0, mode="none")
+        self.kT = kT
+
+    def _pack(self, d):
+        return np.array([d["A"], d["gamma"], d["s"], 0.0])
+
+    def _unpack(self, raw):
+        return dict(A=float(raw[0]), gamma=float(raw[1]), s=float(raw[2]))
+
+    def _attach(self, sim):
+        # DPD uses RNGs: warn if the seed was not set (src/pair.py:236-239)
+        sim._warn_if_seed_unset()
+        super()._attach(sim)
+
+    def _launch(self, stream, timestep):
+        st = self._state
+        d = _lib.DPDArgs()
+        d.pair = self._pair_args()
+        d.d_vel = st.vel.data_ptr()
+        d.d_tag = st.tag.data_ptr()
+        ts = self._sim.timestep if timestep is None else timestep
+        d.timestep = int(ts)
+        d.deltaT = float(self._sim.dt)
+        d.T = float(self.kT(ts)) if callable(self.kT) else float(self.kT)
+        d.seed = int(self._sim.seed) & 0xFFFF
+        _lib.check(_lib.lib().azp_dpd_forces_general_weight(C.byref(d), self._tables["params"].data_ptr(), stream),
+                   self._entry)
+
+
+class DPDConservativeGeneralWeight(Pair):
+    """Conservative part only: the reference also registers
+    ``PotentialPairConservativeGeneralWeight``
+    (src/export_PotentialPairDPDThermo.cc.inc:33-35)."""
+
+    _cpp_class_name = "PotentialPairConservativeGeneralWeight"
+    _entry = "azp_pair_forces_dpd_conservative"
+    _schema = dict(A=float, gamma=float, s=float)
+    _accepted_modes = ("none",)
+
+    def __init__(self, nlist, default_r_cut=None):
+        super().__init__(nlist, default_r_cut=default_r_cut, default_r_on=0.0, mode="none")
+
+    _pack = DPDGeneralWeight._pack
+    _unpack = DPDGeneralWeight._unpack
+
+
+class TwoPatchMorse(Pair):
+    """Two-patch Morse anisotropic pair potential (reference
+    ``src/pair.py:429-525``; HOOMD ``AnisotropicPair``: no ``r_on``, modes
+    ``"none"`` / ``"shift"``)."""
+
+    _cpp_class_name = "AnisoPotentialPairTwoPatchMorse"
+    _entry = "azp_aniso_forces_two_patch_morse"
+    _schema = dict(M_d=float, M_r=float, r_eq=float, omega=float, alpha=float, repulsion=bool)
+    _param_doubles = 6
+    _accepted_modes = ("none", "shift")
+
+    def __init__(self, nlist, default_r_cut=None, mode="none"):
+        super().__init__(nlist, default_r_cut=default_r_cut, default_r_on=0.0, mode=mode)
+
+    def _pack(self, d):
+        out = np.zeros(6)
+        _lib.lib().azp_tpm_params_make(d["M_d"], d["M_r"], d["r_eq"], d["omega"], d["alpha"], int(d["repulsion"]),
+                                       out.ctypes.data)
+        return out
+
+    def _unpack(self, raw):
+        v = [C.c_double() for _ in range(5)]
+        rep = C.c_int()
+        _lib.lib().azp_tpm_params_unpack(raw.ctypes.data, *[C.byref(x) for x in v], C.byref(rep))
+        return dict(M_d=v[0].value, M_r=v[1].value, r_eq=v[2].value, omega=v[3].value, alpha=v[4].value,
+                    repulsion=bool(rep.value))
+
+    def _launch(self, stream, timestep):
+        st = self._state
+        g = _lib.AnisoArgs()
+        g.pair = self._pair_args()
+        g.d_orientation = st.orientation.data_ptr()
+        g.d_torque = self._torque.data_ptr()
+        _lib.check(_lib.lib().azp_aniso_forces_two_patch_morse(C.byref(g), self._tables["params"].data_ptr(), stream),
+                   self._entry)
+
+
+__all__ = ["Colloid", "DPDGeneralWeight", "DPDConservativeGeneralWeight", "ExpandedYukawa", "Hertz",
+           "PerturbedLennardJones", "TwoPatchMorse"]

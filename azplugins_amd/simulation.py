@@ -1,0 +1,122 @@
+"""Minimal simulation driver: the slice of ``hoomd.Simulation`` /
+``hoomd.md.Integrator`` the reference's tests exercise -- attach forces to a
+state, ``run(0)`` to evaluate them, and a velocity-Verlet NVE step
+(``hoomd.md.methods.ConstantVolume``) so thermostatting pair forces can be
+validated as in src/pytest/test_pair_dpd.py.
+"""
+
+import warnings
+
+import numpy as np
+
+from . import _lib
+from .state import State
+
+
+class ConstantVolume:
+    """NVE integration method (velocity Verlet) on all particles."""
+
+    def __init__(self, filter=None):
+        self.filter = filter
+
+
+class Integrator:
+    """``hoomd.md.Integrator`` reduced: ``dt``, ``forces``, ``methods``."""
+
+    def __init__(self, dt, forces=None, methods=None):
+        self.dt = float(dt)
+        self.forces = list(forces) if forces is not None else []
+        self.methods = list(methods) if methods is not None else []
+
+
+class _Operations:
+    def __init__(self):
+        self.integrator = None
+
+
+class Simulation:
+    def __init__(self, device="cuda:0", seed=None):
+        self.device = device
+        self.seed = seed
+        self.state = None
+        self.timestep = 0
+        self.operations = _Operations()
+        self._attached = []
+
+    def _warn_if_seed_unset(self):
+        if self.seed is None:
+            warnings.warn("Simulation.seed is not set, using default seed=0", RuntimeWarning)
+            self.seed = 0
+
+    def create_state_from_snapshot(self, snapshot):
+        self.state = State(snapshot, self.device)
+        return self.state
+
+    @property
+    def dt(self):
+        integ = self.operations.integrator
+        return integ.dt if integ is not None else 0.0
+
+    def _attach_all(self):
+        integ = self.operations.integrator
+        if integ is None:
+            raise _lib.AzpError("Simulation.operations.integrator is not set")
+        if self.state is None:
+            raise _lib.AzpError("Simulation has no state; call create_state_from_snapshot first")
+        for f in integ.forces:
+            if f not in self._attached or f._state is not self.state:
+                f._attach(self)
+                if f not in self._attached:
+                    self._attached.append(f)
+
+    def _compute_forces(self):
+        import torch
+
+        st = self.state
+        st.net_force.zero_()
+        for f in self.operations.integrator.forces:
+            f.compute(self.timestep)
+            st.net_force += f.force_tensor
+
+    def run(self, steps):
+        import torch
+
+        self._attach_all()
+        integ = self.operations.integrator
+        st = self.state
+        self._compute_forces()
+        if steps == 0 or not integ.methods:
+            return
+        dt = integ.dt
+        L = torch.tensor(st.box.L, dtype=torch.float64, device=st.device)
+        for _ in range(steps):
+            # velocity Verlet, first half: v += a dt/2 ; x += v dt ; wrap
+            m = st.vel[: st.N, 3:4]
+            st.vel[: st.N, :3] += 0.5 * dt * st.net_force[:, :3] / m
+            x = st.pos[: st.N, :3] + dt * st.vel[: st.N, :3]
+            x = x - L * torch.floor(x / L + 0.5)
+            st.pos[: st.N, :3] = x
+            st.position_generation += 1
+            self.timestep += 1
+            self._compute_forces()
+            st.vel[: st.N, :3] += 0.5 * dt * st.net_force[:, :3] / m
+
+    def kinetic_temperature(self):
+        """Instantaneous kT = 2 KE / (3 N - 3) (HOOMD ThermodynamicQuantities)."""
+        st = self.state
+        v = st.vel[: st.N]
+        ke = 0.5 * float((v[:, 3] * (v[:, :3] ** 2).sum(dim=1)).sum().item())
+        return 2.0 * ke / (3 * st.N - 3)
+
+    def thermalize_particle_momenta(self, kT, seed=12345):
+        """Maxwell-Boltzmann velocities with zero total momentum."""
+        import torch
+
+        from .synthetic import normal
+
+        st = self.state
+        tag = np.arange(st.N, dtype=np.uint64)
+        m = st.vel[: st.N, 3].cpu().numpy()
+        v = np.stack([normal(seed, tag, c) for c in range(3)], axis=1) * np.sqrt(kT / m)[:, None]
+        v -= (v * m[:, None]).sum(axis=0) / m.sum()
+        st.vel[: st.N, :3] = torch.from_numpy(v).to(st.device)

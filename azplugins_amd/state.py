@@ -1,0 +1,259 @@
+"""Host snapshot and device state: the minimal stand-in for the HOOMD-blue
+objects the reference's force classes are attached to (``hoomd.Snapshot``,
+``hoomd.State`` / ``ParticleData``). Device memory is held in torch tensors
+(plumbing only); the layouts are HOOMD's:
+
+* ``pos``   (n_max, 4) float64: x, y, z, type index in the low 32 bits of w
+* ``vel``   (n_max, 4) float64: vx, vy, vz, mass
+* ``orientation`` (n_max, 4) float64 quaternion, scalar part first
+* ``tag``   (n_max,) uint32 (stored as int32 bit pattern)
+"""
+
+import numpy as np
+
+from . import _lib
+from .synthetic import pos4 as _pos4
+
+
+class Box:
+    """Triclinic periodic box centred on the origin (HOOMD ``BoxDim``)."""
+
+    def __init__(self, Lx, Ly=None, Lz=None, xy=0.0, xz=0.0, yz=0.0, periodic=(True, True, True)):
+        self.Lx = float(Lx)
+        self.Ly = float(Lx if Ly is None else Ly)
+        self.Lz = float(Lx if Lz is None else Lz)
+        self.xy, self.xz, self.yz = float(xy), float(xz), float(yz)
+        self.periodic = tuple(bool(p) for p in periodic)
+
+    @classmethod
+    def cube(cls, L):
+        return cls(L, L, L)
+
+    @classmethod
+    def from_box(cls, box):
+        if isinstance(box, Box):
+            return box
+        box = list(box)
+        if len(box) == 3:
+            return cls(*box)
+        return cls(*box[:6])
+
+    @property
+    def L(self):
+        return np.array([self.Lx, self.Ly, self.Lz])
+
+    @property
+    def is_triclinic(self):
+        return self.xy != 0.0 or self.xz != 0.0 or self.yz != 0.0
+
+    def to_c(self):
+        return _lib.make_box((self.Lx, self.Ly, self.Lz), (self.xy, self.xz, self.yz), [int(p) for p in self.periodic])
+
+    def __repr__(self):
+        return "Box(Lx=%g, Ly=%g, Lz=%g, xy=%g, xz=%g, yz=%g)" % (self.Lx, self.Ly, self.Lz, self.xy, self.xz, self.yz)
+
+
+class _Particles:
+    def __init__(self):
+        self._N = 0
+        self.types = ["A"]
+        self._alloc(0)
+
+    def _alloc(self, n):
+        self.position = np.zeros((n, 3))
+        self.typeid = np.zeros(n, dtype=np.uint32)
+        self.orientation = np.tile(np.array([1.0, 0.0, 0.0, 0.0]), (n, 1))
+        self.velocity = np.zeros((n, 3))
+        self.mass = np.ones(n)
+        self.moment_inertia = np.zeros((n, 3))
+        self.tag = np.arange(n, dtype=np.uint32)
+
+    @property
+    def N(self):
+        return self._N
+
+    @N.setter
+    def N(self, n):
+        self._N = int(n)
+        self._alloc(self._N)
+
+
+class _Bonds:
+    def __init__(self):
+        self._N = 0
+        self.types = []
+        self.group = np.zeros((0, 2), dtype=np.uint32)
+        self.typeid = np.zeros(0, dtype=np.uint32)
+
+    @property
+    def N(self):
+        return self._N
+
+    @N.setter
+    def N(self, n):
+        self._N = int(n)
+        self.group = np.zeros((self._N, 2), dtype=np.uint32)
+        self.typeid = np.zeros(self._N, dtype=np.uint32)
+
+
+class _Configuration:
+    def __init__(self):
+        self.box = Box(1.0)
+        self.dimensions = 3
+
+
+class Snapshot:
+    """Host-side system description with ``hoomd.Snapshot``'s attribute names
+    (``particles.N/position/typeid/types/orientation/velocity/mass``,
+    ``bonds.N/group/typeid/types``, ``configuration.box``)."""
+
+    def __init__(self):
+        self.particles = _Particles()
+        self.bonds = _Bonds()
+        self.configuration = _Configuration()
+
+    @classmethod
+    def from_arrays(cls, xyz, box, typeid=None, types=("A",), orientation=None, velocity=None, tag=None, bonds=None,
+                    bond_typeid=None, bond_types=("A-A",)):
+        s = cls()
+        xyz = np.asarray(xyz, dtype=np.float64)
+        s.particles.N = xyz.shape[0]
+        s.particles.position[:] = xyz
+        s.particles.types = list(types)
+        if typeid is not None:
+            s.particles.typeid[:] = typeid
+        if orientation is not None:
+            s.particles.orientation[:] = orientation
+        if velocity is not None:
+            s.particles.velocity[:] = velocity
+        if tag is not None:
+            s.particles.tag[:] = tag
+        s.configuration.box = Box.from_box(box)
+        if bonds is not None:
+            bonds = np.asarray(bonds, dtype=np.uint32).reshape(-1, 2)
+            s.bonds.N = bonds.shape[0]
+            s.bonds.group[:] = bonds
+            s.bonds.types = list(bond_types)
+            if bond_typeid is not None:
+                s.bonds.typeid[:] = bond_typeid
+        return s
+
+
+def two_particle_snapshot(particle_types=("A",), d=1.0, L=20.0):
+    """HOOMD conftest's ``two_particle_snapshot_factory`` restated: two particles
+    at (-d/2, 0, 0) and (+d/2, 0, 0) in a cubic box (used by every 2-particle
+    reference test, e.g. src/pytest/test_pair.py:319-321)."""
+    s = Snapshot()
+    s.particles.N = 2
+    s.particles.types = list(particle_types)
+    s.particles.position[:] = [[-d / 2.0, 0.0, 0.0], [d / 2.0, 0.0, 0.0]]
+    s.configuration.box = Box.cube(L)
+    return s
+
+
+def bonded_two_particle_snapshot(bond_types=None, **kwargs):
+    """src/conftest.py:10-24 restated: one bond [0, 1] of type "A-A"."""
+    s = two_particle_snapshot(**kwargs)
+    s.bonds.N = 1
+    s.bonds.types = list(bond_types) if bond_types is not None else ["A-A"]
+    s.bonds.group[0] = [0, 1]
+    return s
+
+
+def lattice_snapshot(particle_types=("A",), n=10, a=0.6):
+    """HOOMD conftest's ``lattice_snapshot_factory`` restated: n^3 simple cubic,
+    box n*a (src/pytest/test_pair_dpd.py:15)."""
+    s = Snapshot()
+    s.particles.N = n**3
+    s.particles.types = list(particle_types)
+    g = (np.arange(n) + 0.5) * a - 0.5 * n * a
+    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    s.particles.position[:] = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    s.configuration.box = Box.cube(n * a)
+    return s
+
+
+class State:
+    """Device-resident particle data (HOOMD ``ParticleData`` + ``BondData``)."""
+
+    def __init__(self, snapshot, device):
+        import torch
+
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.AzpError("azplugins_amd states live on an MI355X (device 'cuda:N'); there is no CPU path")
+        p = snapshot.particles
+        self.N = p.N
+        self.n_ghost = 0
+        self.types = list(p.types)
+        self.box = Box.from_box(snapshot.configuration.box)
+        f64 = torch.float64
+        self.pos = torch.from_numpy(_pos4(p.position, p.typeid)).to(self.device)
+        vel = np.zeros((p.N, 4))
+        vel[:, :3] = p.velocity
+        vel[:, 3] = p.mass
+        self.vel = torch.from_numpy(vel).to(self.device)
+        self.orientation = torch.from_numpy(np.ascontiguousarray(p.orientation, dtype=np.float64)).to(self.device)
+        self.tag = torch.from_numpy(np.ascontiguousarray(p.tag, dtype=np.uint32).view(np.int32)).to(self.device)
+        self.net_force = torch.zeros((p.N, 4), dtype=f64, device=self.device)
+        b = snapshot.bonds
+        self.bond_types = list(b.types)
+        self.bond_group = np.ascontiguousarray(b.group, dtype=np.uint32).reshape(-1, 2)
+        self.bond_typeid = np.ascontiguousarray(b.typeid, dtype=np.uint32)
+        self._bond_table = None
+        self.position_generation = 0  # bumped whenever positions change
+
+    @property
+    def n_max(self):
+        return self.N + self.n_ghost
+
+    @property
+    def typeid_host(self):
+        return self.pos[: self.N, 3].cpu().numpy().view(np.int64).astype(np.int64) & 0xFFFFFFFF
+
+    def bond_table(self):
+        """HOOMD's per-particle GPU bond table (``BondData::getGPUTable``):
+        column-major entries (partner index, bond type), the particle's position
+        in the bond, and the per-particle bond count."""
+        import torch
+
+        if self._bond_table is None:
+            N = self.N
+            g = self.bond_group
+            nb = np.zeros(N, dtype=np.uint32)
+            if g.shape[0]:
+                np.add.at(nb, g[:, 0], 1)
+                np.add.at(nb, g[:, 1], 1)
+            width = int(nb.max()) if N and g.shape[0] else 0
+            width = max(width, 1)
+            table = np.zeros((width, N, 2), dtype=np.uint32)
+            bpos = np.zeros((width, N), dtype=np.uint32)
+            fill = np.zeros(N, dtype=np.int64)
+            for which in (0, 1):
+                # vectorised fill, one pass per member slot, stable in bond order
+                members = g[:, which].astype(np.int64)
+                partner = g[:, 1 - which]
+                order = np.argsort(members, kind="stable")
+                m_sorted = members[order]
+                if m_sorted.size:
+                    start = np.r_[0, np.flatnonzero(np.diff(m_sorted)) + 1]
+                    rank = np.arange(m_sorted.size) - np.repeat(start, np.diff(np.r_[start, m_sorted.size]))
+                    slot = fill[m_sorted] + rank
+                    table[slot, m_sorted, 0] = partner[order]
+                    table[slot, m_sorted, 1] = self.bond_typeid[order]
+                    bpos[slot, m_sorted] = which
+                    np.add.at(fill, members, 1)
+            self._bond_table = dict(
+                table=torch.from_numpy(table.view(np.int32)).to(self.device),
+                bond_pos=torch.from_numpy(bpos.view(np.int32)).to(self.device),
+                n_bonds=torch.from_numpy(nb.view(np.int32)).to(self.device),
+                pitch=N,
+                width=width,
+            )
+        return self._bond_table
+
+    def exclusion_table(self):
+        """Bonded partners as neighbor-list exclusions (HOOMD's default
+        ``exclusions=('bond',)``): (n_excl int32[N], excl int32[width, N])."""
+        t = self.bond_table()
+        return t["n_bonds"], t["table"][:, :, 0].contiguous(), t["pitch"]

@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Benchmark of the force-compute hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ns|c2|...]
+
+Metric (BASELINE.json): particle-steps/s of the PerturbedLennardJones pair
+force at N=1,048,576, rho*=0.8, r_cut=3.0 (FP64, full neighbor list, buffer
+0.4), plus the achieved algorithmic HBM GB/s against the MI355X roofline.
+
+A "step" is one pass of the force kernel(s) over the whole system on a static
+neighbor list, inputs resident in HBM. Prints ONE JSON line on rank 0.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # spec peak, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
+HBM_COPY_GBS = 6290.0      # measured float4 copy on the same guide
+
+
+def alg_bytes_per_particle(mean_neigh, S=8, extra=0):
+    """4S pos + 4 n_neigh + 8 head + 4<n> nlist + 4S force (+ extra)."""
+    return 4 * S + 4 + 8 + 4.0 * mean_neigh + 4 * S + extra
+
+
+def make_workload(name):
+    from azplugins_amd import synthetic as syn
+
+    if name == "ns":
+        return syn.config_north_star(64)
+    if name == "ns-small":
+        return syn.config_north_star(16)
+    if name == "c2":
+        return syn.config_plj_sc(64)
+    raise SystemExit("unknown workload %r" % name)
+
+
+def cpu_baseline(workload, reps=5):
+    """HOOMD-equivalent CPU loop restated (oracle): half neighbor list, third-law
+    scatter, FP64, ONE core (HOOMD's per-rank CPU execution model), timed on
+    this host. Bounded sample: the same lattice, density, potential and cutoff
+    at 1/8 of the particle count (per-particle cost is size-independent)."""
+    import oracle
+    from azplugins_amd import synthetic as syn
+
+    cfg = syn.config_north_star(32) if workload.startswith("ns") else syn.config_plj_sc(40)
+    pos = syn.pos4(cfg["xyz"])
+    box = oracle.make_box(cfg["L"])
+    params = oracle.pack_pair_params(cfg["potential"], cfg["params"])
+    nl = oracle.build_nlist(pos, box, cfg["r_cut"] + cfg["r_buff"], half=True)
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        oracle.pair_forces(cfg["potential"], pos, box, nl, params, cfg["r_cut"], mode="none", half=True)
+        ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    N = pos.shape[0]
+    out = dict(value=N / t, unit="particle-steps/s", cores=1, kind="port",
+               sample="%s: same lattice/density/potential, N=%d (1/8 of the workload), half list, median of %d "
+                      "reps; oracle = HOOMD-equivalent loop restated, not the HOOMD binary" % (cfg["name"], N, reps))
+    # best-effort all-core figure (OpenMP over particles, full list)
+    ncores = os.cpu_count() or 1
+    nl_full = oracle.build_nlist(pos, box, cfg["r_cut"] + cfg["r_buff"], half=False)
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        oracle.pair_forces(cfg["potential"], pos, box, nl_full, params, cfg["r_cut"], mode="none", nthreads=ncores)
+        ts.append(time.perf_counter() - t0)
+    out["all_cores"] = dict(value=N / float(np.median(ts)), cores=ncores)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="ns")
+    ap.add_argument("--tpp", type=int, default=0, help="threads per particle (0 = library heuristic)")
+    ap.add_argument("--block-size", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="none", choices=["none", "shift", "xplor"])
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the force path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+
+    if world > 1:
+        from azplugins_amd import decomposition
+
+        return decomposition.bench_main(args, rank, world, local_rank)
+
+    import azplugins_amd as azp
+
+    cfg = make_workload(args.workload)
+    N = cfg["xyz"].shape[0]
+    snap = azp.Snapshot.from_arrays(cfg["xyz"], cfg["L"])
+    sim = azp.Simulation(device=dev, seed=1)
+    sim.create_state_from_snapshot(snap)
+    nl = azp.nlist.Cell(buffer=cfg["r_buff"])
+    pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=cfg["r_cut"], mode=args.mode)
+    pot.params[("A", "A")] = cfg["params"]
+    pot.threads_per_particle = args.tpp
+    pot.block_size = args.block_size
+    sim.operations.integrator = azp.Integrator(dt=0.005, forces=[pot])
+    sim.run(0)  # attaches, builds the neighbor list on the GPU, first force evaluation
+    mean_neigh = nl.size / N
+
+    for _ in range(args.warmup):
+        pot.compute(0)
+    torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        pot.compute(0)
+    ev1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
+    ms_per_step = wall * 1e3 / args.steps
+
+    value = N * args.steps / wall
+    b_alg = alg_bytes_per_particle(mean_neigh)
+    achieved = b_alg * N / (kernel_ms * 1e-3) / 1e9
+    launch = azp._lib.last_launch()
+    out = {
+        "metric": "particle-steps/sec, PerturbedLennardJones pair force",
+        "value": value,
+        "unit": "particle-steps/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "%s: PerturbedLennardJones N=%d rho*=0.8 r_cut=%.1f buffer=%.1f mode=%s, jittered %s lattice, "
+                        "full neighbor list <n>=%.2f" % (cfg["name"], N, cfg["r_cut"], cfg["r_buff"], args.mode,
+                                                        "FCC" if args.workload.startswith("ns") else "SC", mean_neigh),
+            "N": N,
+            "mean_neighbors": mean_neigh,
+            "launch": launch,
+            "parallelism": "1 GPU",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
+            "traffic": None,
+            "kernel": "azp::pair_forces_kernel<EvalPLJ>",
+            "kernel_ms": kernel_ms,
+            "algorithmic_bytes_per_particle": b_alg,
+        },
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.workload)
+        out["cpu_baseline"]["gpu_over_cpu_1core"] = value / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,264 @@
+/*
+ * azp.h -- C ABI of libazp: MI355X (gfx950) force-compute kernels for the
+ * azplugins pair / bond potentials.
+ *
+ * This is the drop-in boundary. Every entry point replaces one kernel-driver
+ * template instantiation that the reference (stattlab/azplugins v1.1.0)
+ * requests from HOOMD-blue v5:
+ *
+ *   azp_pair_forces_*            <- hoomd::md::kernel::gpu_compute_pair_forces<E>
+ *                                   (src/PotentialPairGPUKernel.cu.inc:25-28)
+ *   azp_dpd_forces_general_weight<- gpu_compute_dpd_forces<DPDPairEvaluatorGeneralWeight>
+ *                                   (src/PotentialPairDPDThermoGPUKernel.cu.inc:21-24)
+ *   azp_aniso_forces_two_patch_morse
+ *                                <- gpu_compute_pair_aniso_forces<AnisoPairEvaluatorTwoPatchMorse>
+ *                                   (src/AnisoPotentialPairGPUKernel.cu.inc:21-25)
+ *   azp_bond_forces_*            <- gpu_compute_bond_forces<E, 2>
+ *                                   (src/PotentialBondGPUKernel.cu.inc:25-29)
+ *
+ * Conventions (all restated from HOOMD-blue's ForceCompute data model):
+ *   - Scalar = double. Scalar4 arrays are 4 consecutive doubles.
+ *   - d_pos[i]   = (x, y, z, type) with the integer type index stored in the
+ *                  low 32 bits of w (HOOMD __scalar_as_int).
+ *   - d_force[i] = (fx, fy, fz, energy); energy is this particle's half share.
+ *   - d_virial   = 6 rows (xx, xy, xz, yy, yz, zz) of length virial_pitch.
+ *   - d_orientation[i] = quaternion, scalar part first.
+ *   - neighbor list: full storage; neighbors of i are
+ *     d_nlist[d_head_list[i] + k], k < d_n_neigh[i]; indices may point at
+ *     ghost particles (>= N, < n_max).
+ *   - per-type-pair tables (rcutsq, ronsq, params) are indexed
+ *     type_i * ntypes + type_j and must be symmetric.
+ *   - outputs are OVERWRITTEN for all N local particles.
+ *   - all pointers prefixed d_ are device pointers borrowed for the call;
+ *     the library allocates nothing and never synchronises the stream.
+ *   - every function returns 0 on success, a positive hipError_t value if the
+ *     launch failed, or a negative azp_status for invalid arguments; nothing
+ *     throws across this boundary.
+ */
+#ifndef AZP_H_
+#define AZP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AZP_VERSION_MAJOR 0
+#define AZP_VERSION_MINOR 1
+
+typedef enum azp_status
+    {
+    AZP_SUCCESS = 0,
+    AZP_ERROR_INVALID_ARGUMENT = -1,
+    AZP_ERROR_TOO_MANY_TYPES = -2, /* per-type-pair table does not fit in LDS */
+    AZP_ERROR_NO_DEVICE = -3
+    } azp_status;
+
+typedef enum azp_shift_mode
+    {
+    AZP_SHIFT_NONE = 0,
+    AZP_SHIFT_SHIFT = 1,
+    AZP_SHIFT_XPLOR = 2
+    } azp_shift_mode;
+
+/* HOOMD BoxDim fields the kernels need: box centred on the origin. */
+typedef struct azp_box
+    {
+    double L[3];
+    double tilt[3]; /* xy, xz, yz */
+    int32_t periodic[3];
+    int32_t _pad;
+    } azp_box;
+
+/* ---- parameter structs: byte-compatible with the reference's param_type ---- */
+
+/* src/PairEvaluatorPerturbedLennardJones.h:57-66 */
+typedef struct azp_plj_params { double sigma_6, epsilon_x_4, attraction_scale_factor, rwcasq; } azp_plj_params;
+/* src/PairEvaluatorHertz.h:41-47 */
+typedef struct azp_hertz_params { double epsilon; } azp_hertz_params;
+/* src/PairEvaluatorExpandedYukawa.h:44-53 (aligned(32)) */
+typedef struct azp_yukawa_params { double epsilon, kappa, delta, _pad; } azp_yukawa_params;
+/* src/PairEvaluatorColloid.h:48-57 */
+typedef struct azp_colloid_params { double A, a_1, a_2, sigma_3; } azp_colloid_params;
+/* src/DPDPairEvaluatorGeneralWeight.h:53-62 (aligned(32)) */
+typedef struct azp_dpd_params { double A, gamma, s, _pad; } azp_dpd_params;
+/* src/AnisoPairEvaluatorTwoPatchMorse.h:63-69 */
+typedef struct azp_tpm_params { double M_d, M_rinv, r_eq, omega, alpha; uint8_t repulsion; uint8_t _pad[7]; } azp_tpm_params;
+/* src/BondEvaluatorDoubleWell.h:52-61 */
+typedef struct azp_dw_params { double r_1, r_diff, U_1, U_tilt; } azp_dw_params;
+/* src/BondEvaluatorQuartic.h:68-82 */
+typedef struct azp_quartic_params { double k, r_0, b_1, b_2, U_0, sigma_6, epsilon_x_4, delta; } azp_quartic_params;
+
+/* Host-side construction / inspection of the parameter structs: what the
+ * reference does in each struct's pybind11::dict constructor and asDict() /
+ * toPython() (file:line next to each struct above). Pure host functions. */
+void azp_plj_params_make(double epsilon, double sigma, double attraction_scale_factor, azp_plj_params* out);
+void azp_plj_params_unpack(const azp_plj_params* p, double* epsilon, double* sigma, double* attraction_scale_factor);
+void azp_colloid_params_make(double A, double a_1, double a_2, double sigma, azp_colloid_params* out);
+void azp_colloid_params_unpack(const azp_colloid_params* p, double* A, double* a_1, double* a_2, double* sigma);
+void azp_tpm_params_make(double M_d, double M_r, double r_eq, double omega, double alpha, int repulsion,
+                         azp_tpm_params* out);
+void azp_tpm_params_unpack(const azp_tpm_params* p, double* M_d, double* M_r, double* r_eq, double* omega,
+                           double* alpha, int* repulsion);
+void azp_dw_params_make(double r_0, double r_1, double U_1, double U_tilt, azp_dw_params* out);
+void azp_dw_params_unpack(const azp_dw_params* p, double* r_0, double* r_1, double* U_1, double* U_tilt);
+void azp_quartic_params_make(double k, double r_0, double b_1, double b_2, double U_0, double sigma, double epsilon,
+                             double delta, azp_quartic_params* out);
+void azp_quartic_params_unpack(const azp_quartic_params* p, double* k, double* r_0, double* b_1, double* b_2,
+                               double* U_0, double* sigma, double* epsilon, double* delta);
+
+/* ---- pair forces ---- */
+
+/* Mirrors hoomd::md::kernel::pair_args_t (minus charge and devprop). */
+typedef struct azp_pair_args
+    {
+    double* d_force;             /* N x 4, overwritten                              */
+    double* d_virial;            /* 6 x virial_pitch, overwritten if compute_virial */
+    uint64_t virial_pitch;
+    uint32_t N;                  /* local particles                                 */
+    uint32_t n_max;              /* local + ghost particles addressable in d_pos    */
+    const double* d_pos;         /* n_max x 4                                       */
+    azp_box box;
+    const uint32_t* d_n_neigh;   /* N                                               */
+    const uint32_t* d_nlist;
+    const uint64_t* d_head_list; /* N                                               */
+    const double* d_rcutsq;      /* ntypes^2                                        */
+    const double* d_ronsq;       /* ntypes^2 (xplor only; may be NULL otherwise)    */
+    uint64_t size_nlist;         /* total entries in d_nlist (0 = unknown; tuning hint) */
+    uint32_t ntypes;
+    uint32_t shift_mode;         /* azp_shift_mode                                  */
+    uint32_t compute_virial;
+    uint32_t block_size;         /* 0 = library default                             */
+    uint32_t threads_per_particle; /* 0 = library heuristic; else 1,2,4,8,16,32     */
+    uint32_t _pad;
+    double r_list_max;           /* optional: upper bound on the separation of any
+                                    listed pair (r_cut_max + 2 r_buff); lets interior
+                                    particles skip the minimum-image step. 0 = unknown. */
+    } azp_pair_args;
+
+int azp_pair_forces_perturbed_lennard_jones(const azp_pair_args* args, const azp_plj_params* d_params, void* stream);
+int azp_pair_forces_hertz(const azp_pair_args* args, const azp_hertz_params* d_params, void* stream);
+int azp_pair_forces_expanded_yukawa(const azp_pair_args* args, const azp_yukawa_params* d_params, void* stream);
+int azp_pair_forces_colloid(const azp_pair_args* args, const azp_colloid_params* d_params, void* stream);
+/* PotentialPairConservativeGeneralWeight (src/export_PotentialPairDPDThermo.cc.inc:33-35) */
+int azp_pair_forces_dpd_conservative(const azp_pair_args* args, const azp_dpd_params* d_params, void* stream);
+
+/* Mirrors hoomd::md::kernel::dpd_pair_args_t. */
+typedef struct azp_dpd_args
+    {
+    azp_pair_args pair;
+    const double* d_vel;   /* n_max x 4 (vx, vy, vz, mass) */
+    const uint32_t* d_tag; /* n_max                        */
+    uint64_t timestep;
+    double deltaT;
+    double T;              /* kT(timestep)                 */
+    uint16_t seed;
+    uint16_t _pad[3];
+    } azp_dpd_args;
+
+int azp_dpd_forces_general_weight(const azp_dpd_args* args, const azp_dpd_params* d_params, void* stream);
+
+/* Mirrors hoomd::md::kernel::a_pair_args_t. */
+typedef struct azp_aniso_args
+    {
+    azp_pair_args pair;
+    const double* d_orientation; /* n_max x 4 */
+    double* d_torque;            /* N x 4, overwritten */
+    } azp_aniso_args;
+
+int azp_aniso_forces_two_patch_morse(const azp_aniso_args* args, const azp_tpm_params* d_params, void* stream);
+
+/* ---- bond forces ---- */
+
+/* HOOMD group_storage<2>: one entry of the per-particle GPU bond table. */
+typedef struct azp_bond_entry
+    {
+    uint32_t idx;  /* index of the other member of the bond */
+    uint32_t type; /* bond type                             */
+    } azp_bond_entry;
+
+/* Mirrors hoomd::md::kernel::bond_args_t<2>. Table entry b of particle i is
+ * d_gpu_bondlist[b * pitch + i], b < d_gpu_n_bonds[i]; d_gpu_bond_pos[b * pitch + i]
+ * is i's position (0 or 1) inside that bond. */
+typedef struct azp_bond_args
+    {
+    double* d_force;
+    double* d_virial;
+    uint64_t virial_pitch;
+    uint32_t N;
+    uint32_t n_max;
+    const double* d_pos;
+    azp_box box;
+    const azp_bond_entry* d_gpu_bondlist;
+    const uint32_t* d_gpu_bond_pos;
+    const uint32_t* d_gpu_n_bonds;
+    uint64_t pitch;
+    uint32_t n_bond_types;
+    uint32_t compute_virial;
+    uint32_t block_size;
+    uint32_t _pad;
+    } azp_bond_args;
+
+/* d_flags: one device word, set to 1 when an evaluator returned false
+ * (invalid parameters) -- HOOMD turns that into "bond out of bounds". */
+int azp_bond_forces_double_well(const azp_bond_args* args, const azp_dw_params* d_params, unsigned int* d_flags,
+                                void* stream);
+int azp_bond_forces_quartic(const azp_bond_args* args, const azp_quartic_params* d_params, unsigned int* d_flags,
+                            void* stream);
+
+/* ---- neighbor-list build (the step before the path) ----
+ * Cell list -> full Verlet list in the layout the force kernels consume.
+ * The reference consumes hoomd.md.nlist.Cell(buffer=...) (src/pytest/test_pair.py:337);
+ * these kernels produce the same data: d_n_neigh, d_head_list (exclusive scan
+ * of d_n_neigh, done by the caller) and d_nlist, rows compact and ordered by
+ * cell, which is also the gather-friendly order for the force kernels.
+ * Sequence: cell_assign -> (caller: stable sort of d_cell_of -> d_order,
+ * d_cell_sorted) -> cell_bounds -> count -> (caller: exclusive scan) -> fill. */
+typedef struct azp_cell_grid
+    {
+    double lo[3];        /* lower corner of the grid                     */
+    double width[3];     /* cell width, >= largest r_list                */
+    uint32_t dim[3];
+    int32_t periodic[3]; /* 1: cell index wraps; 0: clamped (ghost slab) */
+    } azp_cell_grid;
+
+typedef struct azp_nlist_args
+    {
+    uint32_t N;                 /* rows are built for particles [0, N)        */
+    uint32_t n_total;           /* particles binned (local + ghosts)          */
+    const double* d_pos;        /* n_total x 4                                */
+    azp_box box;
+    azp_cell_grid grid;
+    uint32_t ntypes;
+    uint32_t _pad;
+    const double* d_rlistsq;    /* ntypes^2, (r_cut + r_buff)^2; <= 0 disables the pair */
+    uint32_t* d_cell_of;        /* n_total, written by cell_assign            */
+    const uint32_t* d_cell_sorted; /* n_total, d_cell_of in ascending order   */
+    const uint32_t* d_order;    /* n_total, particle indices in that order    */
+    uint32_t* d_cell_start;     /* ncell + 1, written by cell_bounds          */
+    const uint32_t* d_n_excl;   /* optional: N exclusion counts (NULL = none) */
+    const uint32_t* d_excl;     /* entry e of particle i at e * excl_pitch + i */
+    uint64_t excl_pitch;
+    uint32_t* d_n_neigh;        /* N, written by count                        */
+    const uint64_t* d_head_list; /* N, read by fill                           */
+    uint32_t* d_nlist;          /* written by fill                            */
+    } azp_nlist_args;
+
+int azp_nlist_cell_assign(const azp_nlist_args* args, void* stream);
+int azp_nlist_cell_bounds(const azp_nlist_args* args, void* stream);
+int azp_nlist_count(const azp_nlist_args* args, void* stream);
+int azp_nlist_fill(const azp_nlist_args* args, void* stream);
+
+/* ---- misc ---- */
+int azp_version(void);                    /* major * 1000 + minor       */
+const char* azp_status_string(int status);
+/* Resolved launch configuration of the last pair-force call on this thread
+ * (for benchmarks / profiling reports). */
+void azp_last_launch(uint32_t* block_size, uint32_t* threads_per_particle, uint32_t* grid, uint32_t* lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AZP_H_ */

@@ -1,0 +1,86 @@
+"""Regenerates the committed golden fixtures from the CPU oracle.
+
+    python tests/golden/make_golden.py
+
+* c1_hertz_forces.npz -- BASELINE.json configs[0] in full: Hertz, N=4,096
+  uniform random soft spheres (seed 1), cubic L=16, epsilon=1, r_cut=1.0,
+  buffer 0.4, mode none; forces/energies (N,4) from the oracle's HOOMD-style
+  CPU loop (half list + third-law scatter).
+* sweeps.npz -- per-evaluator dense r-sweeps (256 r values x parameter sets x
+  {shift off, on}) of (force_divr, pair_eng) from the oracle's scalar
+  evaluators, including the branch edges (r ~ r_wca, r_cut, r_eq, r_0).
+
+The oracle itself is pinned by the reference's known-answer cases
+(reference_cases.json); these fixtures freeze its output so that a later change
+to the oracle cannot silently move the target.
+"""
+
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import oracle  # noqa: E402
+from azplugins_amd import synthetic as syn  # noqa: E402
+
+
+def c1():
+    cfg = syn.config_c1()
+    pos = syn.pos4(cfg["xyz"])
+    box = oracle.make_box(cfg["L"])
+    nl = oracle.build_nlist(pos, box, cfg["r_cut"] + cfg["r_buff"], half=True)
+    params = oracle.pack_pair_params("Hertz", cfg["params"])
+    f = oracle.pair_forces("Hertz", pos, box, nl, params, cfg["r_cut"], half=True)
+    np.savez_compressed(os.path.join(HERE, "c1_hertz_forces.npz"), force=f, mean_neighbors=2.0 * nl[0].mean())
+
+
+SWEEPS = {
+    "PerturbedLennardJones": (3.0, [dict(epsilon=1.0, sigma=1.0, attraction_scale_factor=0.5),
+                                    dict(epsilon=2.0, sigma=1.05, attraction_scale_factor=0.0),
+                                    dict(epsilon=0.7, sigma=2.9, attraction_scale_factor=1.0)]),  # rcut < rwca
+    "Hertz": (1.5, [dict(epsilon=2.0), dict(epsilon=0.5), dict(epsilon=0.0)]),
+    "ExpandedYukawa": (3.0, [dict(epsilon=1.0, kappa=1.0, delta=0.5), dict(epsilon=3.0, kappa=3.0, delta=0.0),
+                             dict(epsilon=1.0, kappa=0.1, delta=0.2)]),
+    "Colloid": (6.0, [dict(A=100.0, a_1=0.0, a_2=0.0, sigma=2.0), dict(A=100.0, a_1=1.5, a_2=0.0, sigma=1.05),
+                      dict(A=100.0, a_1=1.5, a_2=0.75, sigma=1.05)]),
+    "DPDConservative": (1.0, [dict(A=25.0, gamma=4.5, s=0.5), dict(A=2.0, gamma=1.0, s=2.0), dict(A=0.0, gamma=4.5, s=2.0)]),
+}
+SWEEP_RMIN = {"PerturbedLennardJones": 0.8, "Hertz": 0.05, "ExpandedYukawa": 0.55, "Colloid": 2.6, "DPDConservative": 0.05}
+
+
+def sweeps():
+    out = {}
+    for name, (r_cut, plist) in SWEEPS.items():
+        r = np.linspace(SWEEP_RMIN[name], 1.05 * r_cut, 256)
+        # add exact branch edges
+        r[100] = 2.0 ** (1.0 / 6.0)
+        r[200] = r_cut
+        res = np.zeros((len(plist), 2, 256, 3))
+        for ip, p in enumerate(plist):
+            for ish, sh in enumerate((False, True)):
+                for ir, rr in enumerate(r):
+                    ok, f, e = oracle.eval_pair(name, p, rr, r_cut, sh)
+                    res[ip, ish, ir] = (ok, f, e)
+        out[name + "_r"] = r
+        out[name] = res
+    r = np.linspace(0.6, 2.6, 256)
+    dw = [dict(r_0=1.0, r_1=2.0, U_1=1.0, U_tilt=0.5), dict(r_0=0.5, r_1=2.5, U_1=5.0, U_tilt=0.0)]
+    qt = [dict(k=1434.3, r_0=1.5, b_1=-0.7589, b_2=0.0, U_0=67.2234, sigma=1.0, epsilon=1.0, delta=0.0),
+          dict(k=1434.3, r_0=1.5, b_1=-0.7589, b_2=0.0, U_0=67.2234, sigma=1.0, epsilon=1.0, delta=0.5)]
+    for name, plist in (("DoubleWell", dw), ("Quartic", qt)):
+        res = np.zeros((len(plist), 256, 3))
+        for ip, p in enumerate(plist):
+            for ir, rr in enumerate(r):
+                res[ip, ir] = oracle.eval_bond(name, p, rr)
+        out[name + "_r"] = r
+        out[name] = res
+    np.savez_compressed(os.path.join(HERE, "sweeps.npz"), **out)
+
+
+if __name__ == "__main__":
+    c1()
+    sweeps()
+    print("golden fixtures written to", HERE)

@@ -1,0 +1,323 @@
+"""Parity of the gfx950 kernels (called through the C ABI) with the CPU oracle on
+identical seeded snapshots.
+
+Tolerances (FP64 path): forces / energies / virials / torques agree with the
+oracle to TOL = 1e-10 of the largest component of the array (the two differ
+only by FMA contraction, the Newton-refined reciprocal and summation order);
+the north-star bar of 1e-5 relative is asserted per particle as well.
+"""
+
+import numpy as np
+import pytest
+
+import helpers as H
+from azplugins_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+NORTH_STAR_TOL = 1e-5
+
+
+def assert_close(got, ref, tol=TOL, what=""):
+    got = np.asarray(got)
+    ref = np.asarray(ref)
+    assert got.shape == ref.shape, what
+    assert np.all(np.isfinite(got)), "%s: non-finite output" % what
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref).max()
+    assert err <= tol * (scale if scale > 0 else 1.0), "%s: max abs err %g vs scale %g" % (what, err, scale)
+
+
+def assert_per_particle(got, ref):
+    """north_star: forces within 1e-5 relative of the CPU reference, per
+    particle (floor: 1e-3 of the largest force so exact zeros do not divide)."""
+    n_ref = np.linalg.norm(ref[:, :3], axis=1)
+    n_err = np.linalg.norm(got[:, :3] - ref[:, :3], axis=1)
+    floor = 1e-3 * n_ref.max()
+    assert np.all(n_err <= NORTH_STAR_TOL * np.maximum(n_ref, floor))
+
+
+PAIR_PARAMS = {
+    "PerturbedLennardJones": lambda i, j: dict(epsilon=1.0 + 0.15 * (i + j), sigma=1.0 - 0.03 * (i + j),
+                                               attraction_scale_factor=0.5 - 0.1 * min(i, j)),
+    "Hertz": lambda i, j: dict(epsilon=2.0 + i + j),
+    "ExpandedYukawa": lambda i, j: dict(epsilon=1.0 + 0.5 * (i + j), kappa=1.2, delta=0.1 * (i + j)),
+    "Colloid": None,  # below
+    "DPDConservative": lambda i, j: dict(A=25.0 - 3 * (i + j), gamma=4.5, s=0.5),
+}
+
+
+def _params_table(oracle, name, T):
+    if name == "Colloid":
+        # type 0 = solvent (a=0), types >= 1 = colloids of radius 0.3, 0.4: covers the
+        # solvent-solvent, colloid-solvent and colloid-colloid branches
+        radius = [0.0, 0.3, 0.4]
+
+        def fn(i, j):
+            return dict(A=40.0 + 5 * (i + j), a_1=radius[i], a_2=radius[j], sigma=0.5)
+    else:
+        fn = PAIR_PARAMS[name]
+    tab = H.sym_table(T, fn)
+    # Colloid needs (a_1, a_2) stored symmetrically, as HOOMD's setParams does
+    return np.array([oracle.pack_pair_params(name, tab[min(i, j)][max(i, j)]) for i in range(T) for j in range(T)])
+
+
+def _config(oracle, T, name):
+    # lattice spacing 1.1 with jitter keeps r_ij >~ 0.85: all potentials finite
+    a = 1.1 if name != "Colloid" else 1.6
+    pos, L, typeid = H.lattice_config(10, a, 0.1 * a, seed=21, ntypes=T)
+    return pos, L
+
+
+@pytest.mark.parametrize("name", ["PerturbedLennardJones", "Hertz", "ExpandedYukawa", "Colloid", "DPDConservative"])
+@pytest.mark.parametrize("T", [1, 3])
+@pytest.mark.parametrize("mode", ["none", "shift", "xplor"])
+def test_pair_parity(oracle, name, T, mode):
+    pos, L = _config(oracle, T, name)
+    box = oracle.make_box(L)
+    r_cut = np.full((T, T), 2.5 if name != "Colloid" else 3.2)
+    if T > 1:
+        r_cut[0, 1] = r_cut[1, 0] = r_cut[0, 0] - 0.3
+    r_on = 0.8 * r_cut
+    if T > 1 and mode == "xplor":
+        r_on[2, 2] = r_cut[2, 2] + 0.1  # r_on > r_cut: xplor degenerates to shift for this pair
+    r_buff = 0.3
+    params = _params_table(oracle, name, T)
+    nl_full = oracle.build_nlist(pos, box, r_cut + r_buff, ntypes=T)
+    nl_half = oracle.build_nlist(pos, box, r_cut + r_buff, ntypes=T, half=True)
+    # reference semantics: HOOMD CPU loop = half list + third-law scatter
+    f_ref, v_ref = oracle.pair_forces(name, pos, box, nl_half, params, r_cut, r_on, mode, ntypes=T, half=True, virial=True)
+    f_gpu, v_gpu = H.gpu_pair_forces(name, pos, (L,), nl_full, params, r_cut, r_on, mode, ntypes=T, virial=True)
+    assert_close(f_gpu[:, :3], f_ref[:, :3], what="force")
+    assert_close(f_gpu[:, 3], f_ref[:, 3], what="energy")
+    assert_close(v_gpu, v_ref, what="virial")
+    assert_per_particle(f_gpu, f_ref)
+    # without the virial the force/energy must be bit-identical to the virial build
+    f2 = H.gpu_pair_forces(name, pos, (L,), nl_full, params, r_cut, r_on, mode, ntypes=T, virial=False)
+    assert np.array_equal(f2, f_gpu)
+
+
+@pytest.mark.parametrize("tpp", [1, 2, 4, 8, 16, 32])
+@pytest.mark.parametrize("block_size", [64, 256])
+def test_pair_launch_shapes(oracle, tpp, block_size):
+    """Every threads-per-particle / block-size variant gives the oracle's answer;
+    N is not a multiple of anything convenient."""
+    cfg = syn.config_plj_sc(9)
+    pos = syn.pos4(cfg["xyz"][:-5])
+    L = cfg["L"]
+    box = oracle.make_box(L)
+    params = oracle.pack_pair_params("PerturbedLennardJones", cfg["params"])
+    nl = oracle.build_nlist(pos, box, 3.0 + 0.4)
+    f_ref = oracle.pair_forces("PerturbedLennardJones", pos, box, nl, params, 3.0, mode="shift")
+    f_gpu = H.gpu_pair_forces("PerturbedLennardJones", pos, (L,), nl, params, 3.0, mode="shift", tpp=tpp,
+                              block_size=block_size)
+    assert_close(f_gpu, f_ref)
+
+
+def test_interior_skip_is_bit_identical(oracle):
+    """The r_list_max hint (interior waves skip the minimum image) must not
+    change a single bit."""
+    cfg = syn.config_plj_sc(14)
+    pos = syn.pos4(cfg["xyz"])
+    L = cfg["L"]
+    box = oracle.make_box(L)
+    params = oracle.pack_pair_params("PerturbedLennardJones", cfg["params"])
+    nl = oracle.build_nlist(pos, box, 3.4)
+    f0 = H.gpu_pair_forces("PerturbedLennardJones", pos, (L,), nl, params, 3.0, r_list_max=0.0)
+    f1 = H.gpu_pair_forces("PerturbedLennardJones", pos, (L,), nl, params, 3.0, r_list_max=3.4)
+    assert np.array_equal(f0, f1)
+    assert_close(f1, oracle.pair_forces("PerturbedLennardJones", pos, box, nl, params, 3.0))
+
+
+def test_ghosts_and_nonperiodic(oracle):
+    """Forces only for the N local particles; neighbors may be ghosts (index >=
+    N); a non-periodic axis is not wrapped."""
+    cfg = syn.config_plj_sc(10)
+    xyz = cfg["xyz"]
+    L = cfg["L"]
+    order = np.argsort(xyz[:, 0] > 0.0, kind="stable")  # x <= 0 first: "local", rest "ghost"
+    pos = syn.pos4(xyz[order])
+    N = int((xyz[:, 0] <= 0.0).sum())
+    box_o = oracle.make_box(L, periodic=(0, 1, 1))
+    params = oracle.pack_pair_params("PerturbedLennardJones", cfg["params"])
+    nl = oracle.build_nlist(pos, box_o, 2.9, N=N)
+    assert nl[2].max() >= N
+    f_ref = oracle.pair_forces("PerturbedLennardJones", pos, box_o, nl, params, 2.5, N=N)
+    f_gpu = H.gpu_pair_forces("PerturbedLennardJones", pos, (L, (0, 0, 0), (0, 1, 1)), nl, params, 2.5, N=N)
+    assert f_gpu.shape == (N, 4)
+    assert_close(f_gpu, f_ref)
+
+
+def test_triclinic_box(oracle):
+    cfg = syn.config_plj_sc(10)
+    pos = syn.pos4(cfg["xyz"])
+    L = cfg["L"]
+    tilt = (0.2, -0.1, 0.15)
+    box_o = oracle.make_box(L, tilt=tilt)
+    params = oracle.pack_pair_params("PerturbedLennardJones", cfg["params"])
+    # neighbor candidates from the orthorhombic list with a generous radius; the
+    # kernels re-evaluate the true triclinic minimum image
+    nl = oracle.build_nlist(pos, oracle.make_box(L), 4.5)
+    f_ref = oracle.pair_forces("PerturbedLennardJones", pos, box_o, nl, params, 2.0, mode="shift")
+    f_gpu = H.gpu_pair_forces("PerturbedLennardJones", pos, (L, tilt), nl, params, 2.0, mode="shift")
+    assert_close(f_gpu, f_ref)
+
+
+def test_empty_rows_and_empty_system(oracle):
+    """Particles with no neighbors get zeros (not stale memory); N = 0 is a no-op."""
+    xyz = np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [5.0, 5.0, 5.0]])
+    pos = syn.pos4(xyz)
+    box = oracle.make_box(20.0)
+    params = oracle.pack_pair_params("Hertz", dict(epsilon=1.0))
+    nl = oracle.build_nlist(pos, box, 1.9)
+    assert nl[0].tolist() == [1, 1, 0]
+    f = H.gpu_pair_forces("Hertz", pos, (20.0,), nl, params, 1.5, virial=True)
+    assert_close(f[0], oracle.pair_forces("Hertz", pos, box, nl, params, 1.5))
+    assert not f[0][2].any() and not f[1][:, 2].any()
+    import ctypes as C
+
+    from azplugins_amd import _lib
+
+    a = _lib.PairArgs()
+    assert _lib.lib().azp_pair_forces_hertz(C.byref(a), 1, None) == 0  # N = 0
+    assert _lib.lib().azp_pair_forces_hertz(None, None, None) == -1
+
+
+def test_hertz_c1_golden(oracle):
+    """BASELINE.json configs[0]: Hertz, N=4,096 random soft spheres, r_cut=1.0,
+    against the oracle and the committed golden fixture."""
+    import os
+
+    cfg = syn.config_c1()
+    pos = syn.pos4(cfg["xyz"])
+    box = oracle.make_box(cfg["L"])
+    params = oracle.pack_pair_params("Hertz", cfg["params"])
+    nl = oracle.build_nlist(pos, box, cfg["r_cut"] + cfg["r_buff"])
+    f_ref = oracle.pair_forces("Hertz", pos, box, nl, params, cfg["r_cut"], half=False)
+    f_gpu = H.gpu_pair_forces("Hertz", pos, (cfg["L"],), nl, params, cfg["r_cut"])
+    assert_close(f_gpu, f_ref)
+    assert_per_particle(f_gpu, f_ref)
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "c1_hertz_forces.npz"))
+    assert_close(f_gpu, gold["force"], tol=1e-12)
+    assert nl[0].mean() == pytest.approx(float(gold["mean_neighbors"]))
+
+
+def test_dpd_thermostat_parity(oracle):
+    """Drag + random + conservative forces with the same Philox stream."""
+    cfg = syn.config_dpd(4096)
+    for T in (1, 2):
+        n = cfg["xyz"].shape[0]
+        typeid = (np.arange(n) % T) if T > 1 else None
+        pos = syn.pos4(cfg["xyz"], typeid)
+        vel = np.zeros((n, 4))
+        vel[:, :3] = cfg["vel"]
+        vel[:, 3] = 1.0
+        box = oracle.make_box(cfg["L"])
+        tab = H.sym_table(T, lambda i, j: dict(A=25.0 - 5 * (i + j), gamma=4.5 + i + j, s=[0.5, 1.0, 2.0][i + j]))
+        params = np.array([oracle.pack_pair_params("DPDGeneralWeight", tab[i][j]) for i in range(T) for j in range(T)])
+        nl_f = oracle.build_nlist(pos, box, 1.4, ntypes=T)
+        nl_h = oracle.build_nlist(pos, box, 1.4, ntypes=T, half=True)
+        kw = dict(kT=1.0, dt=0.01, seed=7, timestep=123456789, ntypes=T)
+        f_ref, v_ref = oracle.dpd_forces(pos, vel, cfg["tag"], box, nl_h, params, 1.0, half=True, virial=True, **kw)
+        f_gpu, v_gpu = H.gpu_dpd_forces(pos, vel, cfg["tag"], (cfg["L"],), nl_f, params, 1.0, virial=True, **kw)
+        assert_close(f_gpu[:, :3], f_ref[:, :3], what="dpd force")
+        assert_close(f_gpu[:, 3], f_ref[:, 3], what="dpd energy")
+        assert_close(v_gpu, v_ref, what="dpd virial")
+        # pairwise noise is antisymmetric: total momentum is conserved
+        assert np.abs(f_gpu[:, :3].sum(axis=0)).max() < 1e-9 * np.abs(f_gpu[:, :3]).max()
+        # a different timestep or seed draws different noise
+        kw2 = dict(kw, timestep=123456790)
+        f_other = H.gpu_dpd_forces(pos, vel, cfg["tag"], (cfg["L"],), nl_f, params, 1.0, **kw2)
+        assert not np.allclose(f_other[:, :3], f_gpu[:, :3])
+        assert np.array_equal(f_other[:, 3], f_gpu[:, 3])  # energy is conservative only
+
+
+def test_dpd_kT_zero_is_deterministic_part(oracle):
+    cfg = syn.config_dpd(2048)
+    n = cfg["xyz"].shape[0]
+    pos = syn.pos4(cfg["xyz"])
+    vel = np.zeros((n, 4))
+    vel[:, 3] = 1.0
+    box = oracle.make_box(cfg["L"])
+    p = oracle.pack_pair_params("DPDGeneralWeight", cfg["params"])
+    nl = oracle.build_nlist(pos, box, 1.4)
+    f_thermo = H.gpu_dpd_forces(pos, vel, cfg["tag"], (cfg["L"],), nl, p, 1.0, kT=0.0, dt=0.01, seed=1, timestep=5)
+    f_cons = H.gpu_pair_forces("DPDConservative", pos, (cfg["L"],), nl, p, 1.0)
+    assert_close(f_thermo, f_cons, tol=1e-13)
+
+
+def test_aniso_parity(oracle):
+    cfg = syn.config_tpm(8, 8, 12)
+    n = cfg["xyz"].shape[0]
+    for T, mode in ((1, "none"), (1, "shift"), (2, "shift")):
+        typeid = (np.arange(n) % T) if T > 1 else None
+        pos = syn.pos4(cfg["xyz"], typeid)
+        box = oracle.make_box(cfg["L"])
+        tab = H.sym_table(T, lambda i, j: dict(cfg["params"], M_d=1.8341 + 0.2 * (i + j), repulsion=bool((i + j) % 2)))
+        params = np.array([oracle.pack_pair_params("TwoPatchMorse", tab[i][j]) for i in range(T) for j in range(T)])
+        nl_f = oracle.build_nlist(pos, box, 2.0, ntypes=T)
+        nl_h = oracle.build_nlist(pos, box, 2.0, ntypes=T, half=True)
+        f_ref, t_ref, v_ref = oracle.aniso_forces_tpm(pos, cfg["orientation"], box, nl_h, params, 1.6, mode, ntypes=T,
+                                                      half=True, virial=True)
+        f_gpu, t_gpu, v_gpu = H.gpu_aniso_forces(pos, cfg["orientation"], (cfg["L"],), nl_f, params, 1.6, mode, ntypes=T,
+                                                 virial=True)
+        assert_close(f_gpu[:, :3], f_ref[:, :3], what="aniso force")
+        assert_close(f_gpu[:, 3], f_ref[:, 3], what="aniso energy")
+        assert_close(t_gpu[:, :3], t_ref[:, :3], what="aniso torque")
+        assert_close(v_gpu, v_ref, what="aniso virial")
+        assert not t_gpu[:, 3].any()
+        assert np.abs(f_ref[:, :3]).max() > 1e-3 and np.abs(t_ref[:, :3]).max() > 1e-3
+
+
+@pytest.mark.parametrize("name", ["DoubleWell", "Quartic"])
+def test_bond_parity(oracle, name):
+    cfg = syn.config_chains(32, 6, 6, 16)
+    pos = syn.pos4(cfg["xyz"])
+    box = oracle.make_box(cfg["L"])
+    bonds = cfg["bonds"]
+    btype = (np.arange(bonds.shape[0]) % 2).astype(np.uint32)
+    if name == "DoubleWell":
+        ps = [dict(r_0=1.0, r_1=1.5, U_1=1.0, U_tilt=0.5), dict(r_0=0.9, r_1=1.3, U_1=2.0, U_tilt=0.0)]
+    else:
+        ps = [dict(k=1434.3, r_0=1.5, b_1=-0.7589, b_2=0.0, U_0=67.2234, sigma=1.0, epsilon=1.0, delta=0.0),
+              dict(k=1000.0, r_0=1.6, b_1=-0.5, b_2=0.1, U_0=50.0, sigma=0.9, epsilon=1.2, delta=0.15)]
+    params = np.array([oracle.pack_bond_params(name, p) for p in ps])
+    f_ref, bad, v_ref = oracle.bond_forces(name, pos, box, bonds, btype, params, virial=True)
+    assert bad == 0
+    f_gpu, flag, v_gpu = H.gpu_bond_forces(name, pos, (cfg["L"],), bonds, btype, params, virial=True)
+    assert flag == 0
+    assert_close(f_gpu[:, :3], f_ref[:, :3], what="bond force")
+    assert_close(f_gpu[:, 3], f_ref[:, 3], what="bond energy")
+    assert_close(v_gpu, v_ref, what="bond virial")
+    # invalid parameters raise the flag and contribute nothing
+    bad_p = params.copy()
+    if name == "DoubleWell":
+        bad_p[1, 1] = 0.0  # r_diff = 0
+    else:
+        bad_p[1, 1] = 0.0  # r_0 = 0
+    f_bad, flag = H.gpu_bond_forces(name, pos, (cfg["L"],), bonds, btype, bad_p)
+    assert flag == 1
+    f_ref_bad, nbad = oracle.bond_forces(name, pos, box, bonds, btype, bad_p)
+    assert nbad == (btype == 1).sum()
+    assert_close(f_bad, f_ref_bad)
+
+
+def test_plj_c2_full_size(oracle):
+    """BASELINE.json configs[1] at full size: PerturbedLJ, N=262,144, rho*=0.8,
+    r_cut=3.0 vs the oracle (OpenMP full-list loop, same arithmetic per pair)
+    plus size-independent properties."""
+    cfg = syn.config_plj_sc(64)
+    pos = syn.pos4(cfg["xyz"])
+    box = oracle.make_box(cfg["L"])
+    params = oracle.pack_pair_params("PerturbedLennardJones", cfg["params"])
+    nl = oracle.build_nlist(pos, box, 3.4)
+    assert nl[0].mean() == pytest.approx(131.7, abs=2.0)
+    f_ref = oracle.pair_forces("PerturbedLennardJones", pos, box, nl, params, 3.0, mode="shift", nthreads=16)
+    f_gpu = H.gpu_pair_forces("PerturbedLennardJones", pos, (cfg["L"],), nl, params, 3.0, mode="shift", r_list_max=3.4)
+    assert_close(f_gpu, f_ref)
+    assert_per_particle(f_gpu, f_ref)
+    # Newton's third law and run-to-run determinism (no atomics on this path)
+    assert np.abs(f_gpu[:, :3].sum(axis=0)).max() < 1e-9 * np.abs(f_gpu[:, :3]).max() * np.sqrt(len(f_gpu))
+    f_again = H.gpu_pair_forces("PerturbedLennardJones", pos, (cfg["L"],), nl, params, 3.0, mode="shift", r_list_max=3.4)
+    assert np.array_equal(f_again, f_gpu)
