@@ -158,6 +158,11 @@ def lib():
                 "libazp.so not found at %s: build it with `make -C %s` (or __graft_entry__.build()); "
                 "there is no CPU fallback" % (LIB_PATH, CSRC)
             )
+        # One HIP runtime per process: torch ships its own libamdhip64.so.7 and
+        # must be loaded first so that libazp binds to the same runtime (the
+        # device pointers and streams handed across the C ABI are torch's).
+        import torch  # noqa: F401
+
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)  # AttributeError if the symbol is missing
