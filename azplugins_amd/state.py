@@ -176,15 +176,18 @@ def lattice_snapshot(particle_types=("A",), n=10, a=0.6):
 class State:
     """Device-resident particle data (HOOMD ``ParticleData`` + ``BondData``)."""
 
-    def __init__(self, snapshot, device):
+    def __init__(self, snapshot, device, n_local=None):
+        """``n_local``: in a domain-decomposed run the snapshot lists this rank's
+        local particles first and its ghosts after them; forces are computed
+        for the first ``n_local`` only."""
         import torch
 
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.AzpError("azplugins_amd states live on an MI355X (device 'cuda:N'); there is no CPU path")
         p = snapshot.particles
-        self.N = p.N
-        self.n_ghost = 0
+        self.N = p.N if n_local is None else int(n_local)
+        self.n_ghost = p.N - self.N
         self.types = list(p.types)
         self.box = Box.from_box(snapshot.configuration.box)
         f64 = torch.float64
@@ -195,7 +198,7 @@ class State:
         self.vel = torch.from_numpy(vel).to(self.device)
         self.orientation = torch.from_numpy(np.ascontiguousarray(p.orientation, dtype=np.float64)).to(self.device)
         self.tag = torch.from_numpy(np.ascontiguousarray(p.tag, dtype=np.uint32).view(np.int32)).to(self.device)
-        self.net_force = torch.zeros((p.N, 4), dtype=f64, device=self.device)
+        self.net_force = torch.zeros((self.N, 4), dtype=f64, device=self.device)
         b = snapshot.bonds
         self.bond_types = list(b.types)
         self.bond_group = np.ascontiguousarray(b.group, dtype=np.uint32).reshape(-1, 2)

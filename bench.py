@@ -104,7 +104,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
 
-    if world > 1:
+    if world > 1 or os.environ.get("AZP_BENCH_FORCE_DD") == "1":  # the env var rehearses the N>1 code path on one GPU
         from azplugins_amd import decomposition
 
         return decomposition.bench_main(args, rank, world, local_rank)
