@@ -85,6 +85,22 @@ class BondArgs(C.Structure):
     ]
 
 
+class PlanInfo(C.Structure):
+    _fields_ = [
+        ("valid", C.c_int32),
+        ("invalid_reason", C.c_int32),
+        ("threads_per_particle", C.c_uint32),
+        ("tile_size", C.c_uint32),
+        ("lds_slots", C.c_uint32),
+        ("n_tiles", C.c_uint32),
+        ("max_stage", C.c_uint32),
+        ("_pad", C.c_uint32),
+        ("total_stage", C.c_uint64),
+        ("compiled_bytes", C.c_uint64),
+        ("builds", C.c_uint64),
+    ]
+
+
 class CellGrid(C.Structure):
     _fields_ = [("lo", C.c_double * 3), ("width", C.c_double * 3), ("dim", C.c_uint32 * 3), ("periodic", C.c_int32 * 3)]
 
@@ -133,6 +149,15 @@ SYMBOLS = {
     "azp_pair_forces_expanded_yukawa": (C.c_int, [C.POINTER(PairArgs), _VP, _VP]),
     "azp_pair_forces_colloid": (C.c_int, [C.POINTER(PairArgs), _VP, _VP]),
     "azp_pair_forces_dpd_conservative": (C.c_int, [C.POINTER(PairArgs), _VP, _VP]),
+    "azp_pair_plan_create": (C.c_int, [C.POINTER(_VP)]),
+    "azp_pair_plan_destroy": (None, [_VP]),
+    "azp_pair_plan_build": (C.c_int, [_VP, C.POINTER(PairArgs), _VP]),
+    "azp_pair_plan_query": (C.c_int, [_VP, C.POINTER(PlanInfo)]),
+    "azp_pair_forces_planned_perturbed_lennard_jones": (C.c_int, [_VP, C.POINTER(PairArgs), _VP, _VP]),
+    "azp_pair_forces_planned_hertz": (C.c_int, [_VP, C.POINTER(PairArgs), _VP, _VP]),
+    "azp_pair_forces_planned_expanded_yukawa": (C.c_int, [_VP, C.POINTER(PairArgs), _VP, _VP]),
+    "azp_pair_forces_planned_colloid": (C.c_int, [_VP, C.POINTER(PairArgs), _VP, _VP]),
+    "azp_pair_forces_planned_dpd_conservative": (C.c_int, [_VP, C.POINTER(PairArgs), _VP, _VP]),
     "azp_dpd_forces_general_weight": (C.c_int, [C.POINTER(DPDArgs), _VP, _VP]),
     "azp_aniso_forces_two_patch_morse": (C.c_int, [C.POINTER(AnisoArgs), _VP, _VP]),
     "azp_bond_forces_double_well": (C.c_int, [C.POINTER(BondArgs), _VP, _VP, _VP]),
@@ -189,6 +214,34 @@ def make_box(L, tilt=(0.0, 0.0, 0.0), periodic=(1, 1, 1)):
         b.tilt[k] = float(tilt[k])
         b.periodic[k] = int(periodic[k])
     return b
+
+
+class PairPlan:
+    """Owner of one azp_pair_plan handle."""
+
+    def __init__(self):
+        self._h = _VP()
+        check(lib().azp_pair_plan_create(C.byref(self._h)), "azp_pair_plan_create")
+
+    def build(self, args, stream):
+        check(lib().azp_pair_plan_build(self._h, C.byref(args), stream), "azp_pair_plan_build")
+
+    def info(self):
+        i = PlanInfo()
+        check(lib().azp_pair_plan_query(self._h, C.byref(i)), "azp_pair_plan_query")
+        return {f[0]: getattr(i, f[0]) for f in PlanInfo._fields_ if f[0] != "_pad"}
+
+    @property
+    def handle(self):
+        return self._h
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().azp_pair_plan_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
 
 
 def last_launch():

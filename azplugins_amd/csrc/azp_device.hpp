@@ -129,17 +129,17 @@ template<int TPP> __device__ __forceinline__ double group_sum(double v)
     }
 
 // ---------------------------------------------------------------------------
-// FP64 reciprocal: v_rcp_f64 seed + two Newton-Raphson steps (<= 1 ulp-ish),
-// ~6 VALU ops instead of the ~12-op IEEE division sequence.
+// FP64 reciprocal: v_rcp_f64 seed (measured on gfx950: relative error 2^-24.4,
+// ~14 issue cycles) + one third-order correction x (1 + e + e^2), e = 1 - a x:
+// error e^3 ~ 2^-73, i.e. correct to rounding (<= 1 ulp), in 3 FMAs instead of
+// the ~12-op IEEE division sequence or the 4 FMAs of two Newton steps.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double fast_rcp(double a)
     {
-    double x = __builtin_amdgcn_rcp(a);
-    double e = __builtin_fma(-a, x, 1.0);
-    x = __builtin_fma(x, e, x);
-    e = __builtin_fma(-a, x, 1.0);
-    x = __builtin_fma(x, e, x);
-    return x;
+    const double x = __builtin_amdgcn_rcp(a);
+    const double e = __builtin_fma(-a, x, 1.0);
+    const double t = __builtin_fma(e, e, e);
+    return __builtin_fma(x, t, x);
     }
 
 // XCD-aware block remap: hardware deals blocks round-robin over the 8 XCDs, so

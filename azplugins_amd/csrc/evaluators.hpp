@@ -30,8 +30,9 @@ struct EvalPLJ
         double c12, c6;   // 12 lj1, 6 lj2
         double lj1, lj2;
         double lam;       // attraction_scale_factor
-        double rwcasq;
-        double wca_add;   // wca_shift - e_cut      (energy offset inside the WCA core)
+        double one_minus_lam;
+        double wca_rsq;   // min(rwcasq, effective rcutsq): inside => WCA core AND inside the cutoff
+        double wca_minus_tail; // (wca_shift - e_cut) - (-e_cut) = wca_shift
         double tail_add;  // -e_cut                 (energy offset in the scaled tail)
         };
     static __device__ __forceinline__ Coeff prepare(const Params& p, double rcutsq, bool energy_shift)
@@ -58,23 +59,35 @@ struct EvalPLJ
         c.lj1 = lj1;
         c.lj2 = lj2;
         c.lam = lam;
-        c.rwcasq = p.rwcasq;
-        c.wca_add = wca_shift - e_cut;
+        c.one_minus_lam = 1.0 - lam;
+        c.wca_rsq = (p.rwcasq < c.rcutsq) ? p.rwcasq : c.rcutsq;
         c.tail_add = -e_cut;
+        c.wca_minus_tail = (wca_shift - e_cut) - c.tail_add;
         return c;
         }
     static __device__ __forceinline__ bool eval(const Coeff& c, double rsq, double& force_divr, double& pair_eng)
         {
+        // Selects are as expensive as FP64 ops on gfx950 (~4 issue cycles each, two
+        // per 64-bit value), so the masks are folded into arithmetic:
+        //   * outside the cutoff the HIGH word of the reciprocal is cleared (one 32-bit
+        //     select): what is left is a denormal (< 1e-308) whose cube underflows to
+        //     exactly 0, so r6inv, the force and the raw energy vanish exactly;
+        //   * m = 1.0 inside the WCA core else 0.0 differs from 0.0 only in its high
+        //     word (one 32-bit select); scale = lam + m (1 - lam), and the energy
+        //     offsets are blended with m as well.
         const bool in = rsq < c.rcutsq;
-        const bool wca = rsq < c.rwcasq;
-        const double r2inv = fast_rcp(rsq);
+        const bool wca = rsq < c.wca_rsq;
+        const double x = fast_rcp(rsq);
+        const double r2inv = __hiloint2double(in ? __double2hiint(x) : 0, __double2loint(x));
+        const double m = __hiloint2double(wca ? 0x3ff00000 : 0, 0);
         const double r6inv = r2inv * r2inv * r2inv;
         const double f = r2inv * r6inv * __builtin_fma(c.c12, r6inv, -c.c6);
         const double e = r6inv * __builtin_fma(c.lj1, r6inv, -c.lj2);
-        const double scale = in ? (wca ? 1.0 : c.lam) : 0.0;
-        const double add = in ? (wca ? c.wca_add : c.tail_add) : 0.0;
+        const double scale = __builtin_fma(m, c.one_minus_lam, c.lam);
         force_divr = f * scale;
-        pair_eng = __builtin_fma(e, scale, add);
+        // energy offset: wca_add inside the core, tail_add in the tail, 0 outside
+        const double tail = in ? c.tail_add : 0.0;
+        pair_eng = __builtin_fma(e, scale, __builtin_fma(m, c.wca_minus_tail, tail));
         return in;
         }
     };

@@ -1,8 +1,15 @@
-// pair_colloid.hip -- C-ABI entry point azp_pair_forces_colloid
-// (see include/azp.h; kernel in pair_kernel.hpp, arithmetic in evaluators.hpp).
-#include "pair_kernel.hpp"
+// pair_colloid.hip -- C-ABI entry points azp_pair_forces_colloid and
+// azp_pair_forces_planned_colloid (see include/azp.h; kernels in
+// pair_kernel.hpp / pair_tiled.hpp, arithmetic in evaluators.hpp).
+#include "pair_tiled.hpp"
 
 extern "C" int azp_pair_forces_colloid(const azp_pair_args* args, const azp_colloid_params* d_params, void* stream)
     {
     return azp::launch_pair<azp::EvalColloid>(args, d_params, stream);
+    }
+
+extern "C" int azp_pair_forces_planned_colloid(azp_pair_plan* plan, const azp_pair_args* args,
+                                                const azp_colloid_params* d_params, void* stream)
+    {
+    return azp::launch_pair_planned<azp::EvalColloid>(plan, args, d_params, stream);
     }

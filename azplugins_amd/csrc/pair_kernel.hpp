@@ -51,7 +51,7 @@ prepare_coeff(const PairKArgs& a, const typename E::Params* params, uint32_t tp)
     return E::prepare(params[tp], rcutsq, energy_shift);
     }
 
-template<class E, int TPP, bool VIRIAL, bool SINGLE, bool WRAP>
+template<class E, int TPP, bool VIRIAL, bool SINGLE, bool XPLOR, bool WRAP>
 __device__ __forceinline__ void pair_loop(const PairKArgs& a, const typename E::Coeff* __restrict__ s_coeff,
                                           const double* __restrict__ s_ronsq, const typename E::Coeff& c0,
                                           double ronsq0, uint32_t sub, uint32_t n, uint64_t head, double3 pi,
@@ -86,7 +86,7 @@ __device__ __forceinline__ void pair_loop(const PairKArgs& a, const typename E::
         if (SINGLE)
             {
             evaluated = E::eval(c0, rsq, force_divr, pair_eng);
-            if (a.shift_mode == AZP_SHIFT_XPLOR && evaluated)
+            if (XPLOR && evaluated)
                 apply_xplor(rsq, ronsq0, c0.rcutsq, force_divr, pair_eng);
             }
         else
@@ -94,7 +94,7 @@ __device__ __forceinline__ void pair_loop(const PairKArgs& a, const typename E::
             const uint32_t tp = (uint32_t)typei * a.ntypes + (uint32_t)typej;
             const typename E::Coeff c = s_coeff[tp];
             evaluated = E::eval(c, rsq, force_divr, pair_eng);
-            if (a.shift_mode == AZP_SHIFT_XPLOR && evaluated)
+            if (XPLOR && evaluated)
                 apply_xplor(rsq, s_ronsq[tp], c.rcutsq, force_divr, pair_eng);
             }
         // E::eval returns force_divr = pair_eng = 0 when not evaluated
@@ -117,7 +117,7 @@ __device__ __forceinline__ void pair_loop(const PairKArgs& a, const typename E::
         }
     }
 
-template<class E, int TPP, bool VIRIAL, bool SINGLE>
+template<class E, int TPP, bool VIRIAL, bool SINGLE, bool XPLOR>
 __global__ void __launch_bounds__(256) pair_forces_kernel(const PairKArgs a, const typename E::Params* __restrict__ params)
     {
     typedef typename E::Coeff Coeff;
@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(256) pair_forces_kernel(const PairKArgs a, con
     if (SINGLE)
         {
         c0 = prepare_coeff<E>(a, params, 0);
-        if (a.shift_mode == AZP_SHIFT_XPLOR)
+        if (XPLOR)
             ronsq0 = a.ronsq[0];
         }
     else
@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256) pair_forces_kernel(const PairKArgs a, con
         for (uint32_t t = threadIdx.x; t < ntp; t += blockDim.x)
             {
             s_coeff[t] = prepare_coeff<E>(a, params, t);
-            s_ronsq[t] = (a.shift_mode == AZP_SHIFT_XPLOR) ? a.ronsq[t] : 0.0;
+            s_ronsq[t] = XPLOR ? a.ronsq[t] : 0.0;
             }
         __syncthreads();
         }
@@ -174,9 +174,9 @@ __global__ void __launch_bounds__(256) pair_forces_kernel(const PairKArgs a, con
         wrap = !__all(interior);
         }
     if (wrap)
-        pair_loop<E, TPP, VIRIAL, SINGLE, true>(a, s_coeff, s_ronsq, c0, ronsq0, sub, n, head, pi, typei, fx, fy, fz, pe, v);
+        pair_loop<E, TPP, VIRIAL, SINGLE, XPLOR, true>(a, s_coeff, s_ronsq, c0, ronsq0, sub, n, head, pi, typei, fx, fy, fz, pe, v);
     else
-        pair_loop<E, TPP, VIRIAL, SINGLE, false>(a, s_coeff, s_ronsq, c0, ronsq0, sub, n, head, pi, typei, fx, fy, fz, pe, v);
+        pair_loop<E, TPP, VIRIAL, SINGLE, XPLOR, false>(a, s_coeff, s_ronsq, c0, ronsq0, sub, n, head, pi, typei, fx, fy, fz, pe, v);
 
     fx = group_sum<TPP>(fx);
     fy = group_sum<TPP>(fy);
@@ -219,9 +219,9 @@ inline uint32_t choose_tpp(const azp_pair_args& args)
     return tpp;
     }
 
-template<class E, int TPP, bool VIRIAL, bool SINGLE>
-int launch_pair_instance(const azp_pair_args& args, const PairKArgs& k, const typename E::Params* d_params,
-                         uint32_t block_size, hipStream_t stream)
+template<class E, int TPP, bool VIRIAL, bool SINGLE, bool XPLOR>
+int launch_pair_instance2(const azp_pair_args& args, const PairKArgs& k, const typename E::Params* d_params,
+                          uint32_t block_size, hipStream_t stream)
     {
     PairKArgs ka = k;
     const uint32_t groups_per_block = block_size / TPP;
@@ -233,7 +233,7 @@ int launch_pair_instance(const azp_pair_args& args, const PairKArgs& k, const ty
         lds = (sizeof(typename E::Coeff) + sizeof(double)) * (size_t)args.ntypes * args.ntypes;
     if (lds > 160 * 1024)
         return AZP_ERROR_TOO_MANY_TYPES;
-    auto kern = pair_forces_kernel<E, TPP, VIRIAL, SINGLE>;
+    auto kern = pair_forces_kernel<E, TPP, VIRIAL, SINGLE, XPLOR>;
     if (lds > 64 * 1024)
         {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -245,6 +245,15 @@ int launch_pair_instance(const azp_pair_args& args, const PairKArgs& k, const ty
     li.block_size = block_size; li.tpp = TPP; li.grid = nblocks; li.lds_bytes = (uint32_t)lds;
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(block_size), lds, stream, ka, d_params);
     return (int)hipGetLastError();
+    }
+
+template<class E, int TPP, bool VIRIAL, bool SINGLE>
+int launch_pair_instance(const azp_pair_args& args, const PairKArgs& k, const typename E::Params* d_params,
+                         uint32_t block_size, hipStream_t stream)
+    {
+    if (args.shift_mode == AZP_SHIFT_XPLOR)
+        return launch_pair_instance2<E, TPP, VIRIAL, SINGLE, true>(args, k, d_params, block_size, stream);
+    return launch_pair_instance2<E, TPP, VIRIAL, SINGLE, false>(args, k, d_params, block_size, stream);
     }
 
 template<class E, bool VIRIAL, bool SINGLE>

@@ -1,0 +1,66 @@
+// pair_plan.hpp -- "tile plan": a compiled form of a HOOMD neighbor list for the
+// tile-staged pair kernel (pair_tiled.hpp).
+//
+// Why: the generic kernel gathers each neighbor position from L1/L2 (two tag
+// lookups per neighbor per lane) and is bound by the L1 lookup rate, not by HBM
+// or FP64 issue (profiles/r01_plj_generic_tpp8_summary.csv). The plan moves the
+// gather into LDS:
+//
+//   tile   = TB consecutive (spatially sorted) particles = one workgroup
+//   stage  = sorted unique list of every particle any tile member lists as a
+//            neighbor; the force kernel loads those positions ONCE per tile with
+//            coalesced-ish loads into LDS (SoA x|y|z), already shifted to the
+//            periodic image nearest the tile, so the inner loop needs no
+//            minimum-image arithmetic
+//   cnl    = compiled neighbor list: per wave ("slice") a sliced-ELL array of
+//            16-byte chunks, chunk (k, lane) at slice_head + k*64 + lane, each
+//            holding 8 x u16 byte offsets (slot*8) into the LDS arrays; rows are
+//            padded with offset 0 = a dummy slot parked far away. Index traffic:
+//            2 B per neighbor, every load a full 1 KiB wave transaction.
+//
+// The plan is rebuilt whenever the neighbor list is rebuilt (every ~10-20 MD
+// steps) and reused by every force call in between.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/azp.h"
+
+namespace azp
+{
+constexpr uint32_t PLAN_HASH_CAP = 8192;     // LDS hash-set capacity per tile (build only)
+constexpr uint32_t PLAN_MAX_STAGE = 4095;    // + dummy slot 0 => <= 4096 LDS slots (u16 offset = slot*8 < 65536)
+constexpr uint32_t PLAN_EMPTY = 0xFFFFFFFFu;
+constexpr double PLAN_FAR = 1.0e30;          // coordinate of the dummy slot
+
+struct PairPlan
+    {
+    // configuration chosen at build time
+    uint32_t tpp = 0;          // lanes per particle (1, 2, 4)
+    uint32_t tile = 0;         // particles per tile = 4 waves * 64 / tpp
+    uint32_t cap = 0;          // LDS slots the force kernel must provide (1024 / 2048 / 4096)
+    // what it was built for
+    uint32_t N = 0, n_max = 0;
+    const uint32_t* nlist_ptr = nullptr;
+    const uint64_t* head_ptr = nullptr;
+    uint64_t size_nlist = 0;
+    bool valid = false;        // false => callers fall back to the generic kernel
+    int invalid_reason = 0;    // 2: a tile's neighbor set exceeds PLAN_MAX_STAGE (e.g. unsorted particles)
+    // sizes
+    uint32_t n_tiles = 0, n_slices = 0;
+    uint32_t max_stage = 0;
+    uint64_t total_stage = 0, total_chunks = 0; // chunks in units of (64 lanes x 16 B)
+    // device buffers (owned)
+    uint32_t* d_tile_nstage = nullptr;     // n_tiles
+    uint64_t* d_tile_head = nullptr;       // n_tiles
+    uint32_t* d_stage_idx = nullptr;       // total_stage
+    uint32_t* d_slice_K = nullptr;         // n_slices
+    uint64_t* d_slice_head = nullptr;      // n_slices (chunk units)
+    uint4* d_cnl = nullptr;                // total_chunks * 64
+    uint32_t* d_flags = nullptr;           // [1] stage overflow, [2] max staged set
+    size_t cap_tiles = 0, cap_slices = 0, cap_stage = 0, cap_cnl = 0;
+    uint64_t builds = 0;
+    };
+
+} // namespace azp

@@ -1,0 +1,370 @@
+// pair_tiled.hpp -- tile-staged pair-force kernel (uses a PairPlan).
+//
+// One workgroup (4 waves) per tile of 256/TPP consecutive particles:
+//   1. stage: the tile's sorted unique neighbor set is loaded once (index list
+//      coalesced, positions semi-coalesced because the list is sorted) into LDS
+//      as SoA x | y | z (| type), shifted to the periodic image nearest the
+//      tile's reference particle. Slot 0 is a dummy parked at 1e30 for padding.
+//   2. loop: each lane reads one 16-byte chunk = 8 u16 byte offsets per
+//      iteration (a wave reads 1 KiB contiguous), then for each of the 8
+//      neighbors three ds_read_b64 gathers and the evaluator. No global gathers,
+//      no minimum image, no row-length test (rows are padded with the dummy),
+//      8 independent pairs in flight per lane.
+//   3. DPP butterfly over the TPP lanes, lane 0 stores force (and virial).
+// Same evaluators, same outputs as pair_kernel.hpp; results agree with it to
+// rounding (the periodic shift is applied to r_j instead of to r_i - r_j).
+#pragma once
+
+#include "pair_kernel.hpp"
+#include "pair_plan.hpp"
+
+namespace azp
+{
+struct TiledKArgs
+    {
+    PairKArgs p;
+    const uint32_t* tile_nstage;
+    const uint64_t* tile_head;
+    const uint32_t* stage_idx;
+    const uint32_t* slice_K;
+    const uint64_t* slice_head;
+    const uint4* cnl;
+    };
+
+// Half a chunk's worth of gathered neighbor data (4 neighbors of this lane).
+struct TileBatch
+    {
+    double x[4], y[4], z[4];
+    uint32_t off[4];
+    };
+
+// phase 1: issue the 12 LDS gathers of half H (0 or 1) of a chunk
+template<int CAP, int H> __device__ __forceinline__ void tile_gather(TileBatch& b, const uint4& u, const char* bx)
+    {
+    const uint32_t w0 = H ? u.z : u.x, w1 = H ? u.w : u.y;
+    b.off[0] = w0 & 0xffffu;
+    b.off[1] = w0 >> 16;
+    b.off[2] = w1 & 0xffffu;
+    b.off[3] = w1 >> 16;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        {
+        b.x[e] = *reinterpret_cast<const double*>(bx + b.off[e]);
+        b.y[e] = *reinterpret_cast<const double*>(bx + b.off[e] + CAP * 8);
+        b.z[e] = *reinterpret_cast<const double*>(bx + b.off[e] + CAP * 16);
+        }
+    }
+
+// phase 2: arithmetic on a gathered half chunk
+template<class E, int CAP, bool VIRIAL, bool SINGLE, bool XPLOR, bool WRAP>
+__device__ __forceinline__ void tile_compute(const TileBatch& b, const TiledKArgs& a, const char* bt,
+                                             const typename E::Coeff* __restrict__ s_coeff,
+                                             const double* __restrict__ s_ronsq, const typename E::Coeff& c0, double ronsq0,
+                                             const double3& pi, int typei, double& fx, double& fy, double& fz, double& pe,
+                                             double (&v)[6])
+    {
+    typedef typename E::Coeff Coeff;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        {
+        const uint32_t off = b.off[e];
+        double dx = pi.x - b.x[e], dy = pi.y - b.y[e], dz = pi.z - b.z[e];
+        if (WRAP)
+            min_image(a.p.box, dx, dy, dz);
+        double rsq = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
+        if (WRAP)
+            rsq = (off == 0) ? 1.0e300 : rsq; // the minimum image would fold the padding slot back into the box
+        double force_divr, pair_eng;
+        if (SINGLE)
+            {
+            const bool evaluated = E::eval(c0, rsq, force_divr, pair_eng);
+            if (XPLOR && evaluated)
+                apply_xplor(rsq, ronsq0, c0.rcutsq, force_divr, pair_eng);
+            }
+        else
+            {
+            const int typej = *reinterpret_cast<const int*>(bt + (off >> 1));
+            const uint32_t tp = (uint32_t)typei * a.p.ntypes + (uint32_t)typej;
+            const Coeff cc = s_coeff[tp];
+            const bool evaluated = E::eval(cc, rsq, force_divr, pair_eng);
+            if (XPLOR && evaluated)
+                apply_xplor(rsq, s_ronsq[tp], cc.rcutsq, force_divr, pair_eng);
+            }
+        fx = __builtin_fma(dx, force_divr, fx);
+        fy = __builtin_fma(dy, force_divr, fy);
+        fz = __builtin_fma(dz, force_divr, fz);
+        pe += pair_eng;
+        if (VIRIAL)
+            {
+            const double fxx = force_divr * dx, fyy = force_divr * dy;
+            v[0] = __builtin_fma(fxx, dx, v[0]);
+            v[1] = __builtin_fma(fxx, dy, v[1]);
+            v[2] = __builtin_fma(fxx, dz, v[2]);
+            v[3] = __builtin_fma(fyy, dy, v[3]);
+            v[4] = __builtin_fma(fyy, dz, v[4]);
+            v[5] = __builtin_fma(force_divr * dz, dz, v[5]);
+            }
+        }
+    }
+
+// Inner loop over this lane's chunks, software-pipelined at half-chunk
+// granularity: while the arithmetic of one half (4 pairs) runs, the 12 LDS gathers
+// of the next half and the index load of the next chunk are in flight. WRAP = true
+// re-applies the minimum image to every pair (tiles that are wide compared with the
+// box, triclinic boxes, or no r_list_max hint); WRAP = false trusts the staged
+// image (the common case).
+template<class E, int TPP, int CAP, bool VIRIAL, bool SINGLE, bool XPLOR, bool WRAP>
+__device__ __forceinline__ void tiled_loop(const TiledKArgs& a, const char* bx, const char* bt,
+                                           const typename E::Coeff* __restrict__ s_coeff,
+                                           const double* __restrict__ s_ronsq, const typename E::Coeff& c0, double ronsq0,
+                                           const uint4* __restrict__ chunks, uint32_t K, double3 pi, int typei,
+                                           double& fx, double& fy, double& fz, double& pe, double (&v)[6])
+    {
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    uint4 u = (K > 0) ? chunks[0] : zero4;
+    TileBatch A, B;
+    tile_gather<CAP, 0>(A, u, bx);
+    for (uint32_t kk = 0; kk < K; ++kk)
+        {
+        const uint4 un = (kk + 1 < K) ? chunks[(uint64_t)(kk + 1) * 64] : zero4; // next chunk's indices
+        tile_gather<CAP, 1>(B, u, bx);
+        __builtin_amdgcn_sched_barrier(0);
+        tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(A, a, bt, s_coeff, s_ronsq, c0, ronsq0, pi, typei, fx, fy, fz, pe, v);
+        __builtin_amdgcn_sched_barrier(0);
+        tile_gather<CAP, 0>(A, un, bx); // padding slot when kk + 1 == K: gathered, never used
+        __builtin_amdgcn_sched_barrier(0);
+        tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(B, a, bt, s_coeff, s_ronsq, c0, ronsq0, pi, typei, fx, fy, fz, pe, v);
+        __builtin_amdgcn_sched_barrier(0);
+        u = un;
+        }
+    }
+
+template<class E, int TPP, int CAP, bool VIRIAL, bool SINGLE, bool XPLOR>
+__global__ void __launch_bounds__(256) pair_forces_tiled_kernel(const TiledKArgs a, const typename E::Params* __restrict__ params)
+    {
+    typedef typename E::Coeff Coeff;
+    constexpr int TB = 256 / TPP;
+    constexpr int PW = 64 / TPP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    double* s_x = reinterpret_cast<double*>(s_raw);
+    double* s_y = s_x + CAP;
+    double* s_z = s_y + CAP;
+    int* s_t = reinterpret_cast<int*>(s_z + CAP); // CAP ints, only when !SINGLE
+    Coeff* s_coeff = reinterpret_cast<Coeff*>(s_raw + (size_t)CAP * (SINGLE ? 24 : 28));
+    double* s_ronsq = reinterpret_cast<double*>(s_coeff + (SINGLE ? 0 : a.p.ntypes * a.p.ntypes));
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile = xcd_remap(blockIdx.x, a.p.nblocks_padded);
+    const uint32_t first = tile * TB;
+    if (first >= a.p.N)
+        return;
+
+    Coeff c0;
+    double ronsq0 = 0.0;
+    if (SINGLE)
+        {
+        c0 = prepare_coeff<E>(a.p, params, 0);
+        if (XPLOR)
+            ronsq0 = a.p.ronsq[0];
+        }
+    else
+        {
+        const uint32_t ntp = a.p.ntypes * a.p.ntypes;
+        for (uint32_t t = tid; t < ntp; t += 256)
+            {
+            s_coeff[t] = prepare_coeff<E>(a.p, params, t);
+            s_ronsq[t] = XPLOR ? a.p.ronsq[t] : 0.0;
+            }
+        }
+
+    // ---- stage: positions shifted to the periodic image nearest the tile's
+    // reference particle c ----
+    const uint32_t n_stage = a.tile_nstage[tile];
+    const uint32_t* __restrict__ stage = a.stage_idx + a.tile_head[tile];
+    const double3 c = load_scalar3_of4(a.p.pos, first);
+    if (tid == 0)
+        {
+        s_x[0] = PLAN_FAR; s_y[0] = PLAN_FAR; s_z[0] = PLAN_FAR;
+        if (!SINGLE) s_t[0] = 0;
+        }
+    for (uint32_t s = tid; s < n_stage; s += 256)
+        {
+        const uint32_t j = stage[s];
+        double x, y, z;
+        if (SINGLE)
+            {
+            const double3 pj = load_scalar3_of4(a.p.pos, j);
+            x = pj.x; y = pj.y; z = pj.z;
+            }
+        else
+            {
+            const double4 pj = load_scalar4(a.p.pos, j);
+            x = pj.x; y = pj.y; z = pj.z;
+            s_t[s + 1] = type_from_w(pj.w);
+            }
+        if (!a.p.box.triclinic)
+            {
+            if (a.p.box.px) x = __builtin_fma(-a.p.box.Lx, rint((x - c.x) * a.p.box.Lxinv), x);
+            if (a.p.box.py) y = __builtin_fma(-a.p.box.Ly, rint((y - c.y) * a.p.box.Lyinv), y);
+            if (a.p.box.pz) z = __builtin_fma(-a.p.box.Lz, rint((z - c.z) * a.p.box.Lzinv), z);
+            }
+        s_x[s + 1] = x; s_y[s + 1] = y; s_z[s + 1] = z;
+        }
+
+    // ---- this lane's particle, in the same image frame ----
+    const uint32_t wave = tid >> 6, lane = tid & 63;
+    const uint32_t pl = lane / TPP;
+    const uint32_t idx = first + wave * PW + pl;
+    const bool active = idx < a.p.N;
+    double3 pi = make_double3(0.0, 0.0, 0.0);
+    int typei = 0;
+    // Fast path condition, per tile: every member is closer to c than L/2 minus
+    // the largest possible pair separation, so the staged image of each listed
+    // neighbor IS its minimum image. Otherwise every pair is re-imaged.
+    bool lane_wide = (a.p.r_list_max <= 0.0) || a.p.box.triclinic;
+    if (active)
+        {
+        const double4 p = load_scalar4(a.p.pos, idx);
+        double x = p.x, y = p.y, z = p.z;
+        if (!a.p.box.triclinic)
+            {
+            if (a.p.box.px) x = __builtin_fma(-a.p.box.Lx, rint((x - c.x) * a.p.box.Lxinv), x);
+            if (a.p.box.py) y = __builtin_fma(-a.p.box.Ly, rint((y - c.y) * a.p.box.Lyinv), y);
+            if (a.p.box.pz) z = __builtin_fma(-a.p.box.Lz, rint((z - c.z) * a.p.box.Lzinv), z);
+            lane_wide = lane_wide || (a.p.box.px && fabs(x - c.x) + a.p.r_list_max >= 0.5 * a.p.box.Lx)
+                        || (a.p.box.py && fabs(y - c.y) + a.p.r_list_max >= 0.5 * a.p.box.Ly)
+                        || (a.p.box.pz && fabs(z - c.z) + a.p.r_list_max >= 0.5 * a.p.box.Lz);
+            }
+        pi = make_double3(x, y, z);
+        typei = type_from_w(p.w);
+        }
+    const bool wide = __syncthreads_or(lane_wide); // also publishes the staged tile
+
+    const uint32_t slice = tile * 4 + wave;
+    const uint32_t K = a.slice_K[slice];
+    const uint4* __restrict__ chunks = a.cnl + a.slice_head[slice] * 64ull + lane;
+
+    double fx = 0.0, fy = 0.0, fz = 0.0, pe = 0.0;
+    double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const char* bx = reinterpret_cast<const char*>(s_x);
+    const char* bt = reinterpret_cast<const char*>(s_t);
+    if (wide)
+        tiled_loop<E, TPP, CAP, VIRIAL, SINGLE, XPLOR, true>(a, bx, bt, s_coeff, s_ronsq, c0, ronsq0, chunks, K, pi, typei,
+                                                            fx, fy, fz, pe, v);
+    else
+        tiled_loop<E, TPP, CAP, VIRIAL, SINGLE, XPLOR, false>(a, bx, bt, s_coeff, s_ronsq, c0, ronsq0, chunks, K, pi, typei,
+                                                             fx, fy, fz, pe, v);
+
+    fx = group_sum<TPP>(fx);
+    fy = group_sum<TPP>(fy);
+    fz = group_sum<TPP>(fz);
+    pe = group_sum<TPP>(pe);
+    if (VIRIAL)
+        {
+#pragma unroll
+        for (int cidx = 0; cidx < 6; ++cidx)
+            v[cidx] = group_sum<TPP>(v[cidx]);
+        }
+    if (active && (lane % TPP) == 0)
+        {
+        store_scalar4(a.p.force, idx, fx, fy, fz, 0.5 * pe);
+        if (VIRIAL)
+            {
+#pragma unroll
+            for (int cidx = 0; cidx < 6; ++cidx)
+                a.p.virial[(uint64_t)cidx * a.p.virial_pitch + idx] = 0.5 * v[cidx];
+            }
+        }
+    }
+
+template<class E, int TPP, int CAP, bool VIRIAL, bool SINGLE, bool XPLOR>
+int launch_tiled_instance2(const PairPlan& plan, const azp_pair_args& args, const typename E::Params* d_params,
+                          hipStream_t stream)
+    {
+    TiledKArgs k;
+    k.p = make_pair_kargs(args);
+    k.tile_nstage = plan.d_tile_nstage;
+    k.tile_head = plan.d_tile_head;
+    k.stage_idx = plan.d_stage_idx;
+    k.slice_K = plan.d_slice_K;
+    k.slice_head = plan.d_slice_head;
+    k.cnl = plan.d_cnl;
+    const uint32_t nblocks = (plan.n_tiles + 7u) & ~7u;
+    k.p.nblocks_padded = nblocks;
+    size_t lds = (size_t)CAP * (SINGLE ? 24 : 28);
+    if (!SINGLE)
+        lds += (sizeof(typename E::Coeff) + sizeof(double)) * (size_t)args.ntypes * args.ntypes;
+    if (lds > 160 * 1024)
+        return AZP_ERROR_TOO_MANY_TYPES;
+    auto kern = pair_forces_tiled_kernel<E, TPP, CAP, VIRIAL, SINGLE, XPLOR>;
+    if (lds > 64 * 1024)
+        {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return (int)e;
+        }
+    LaunchInfo& li = last_launch();
+    li.block_size = 256; li.tpp = TPP; li.grid = nblocks; li.lds_bytes = (uint32_t)lds;
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, stream, k, d_params);
+    return (int)hipGetLastError();
+    }
+
+template<class E, int TPP, int CAP, bool VIRIAL, bool SINGLE>
+int launch_tiled_instance(const PairPlan& plan, const azp_pair_args& args, const typename E::Params* d_params,
+                          hipStream_t stream)
+    {
+    if (args.shift_mode == AZP_SHIFT_XPLOR)
+        return launch_tiled_instance2<E, TPP, CAP, VIRIAL, SINGLE, true>(plan, args, d_params, stream);
+    return launch_tiled_instance2<E, TPP, CAP, VIRIAL, SINGLE, false>(plan, args, d_params, stream);
+    }
+
+template<class E, int TPP, bool VIRIAL, bool SINGLE>
+int launch_tiled_cap(const PairPlan& plan, const azp_pair_args& args, const typename E::Params* d_params, hipStream_t s)
+    {
+    switch (plan.cap)
+        {
+    case 1024: return launch_tiled_instance<E, TPP, 1024, VIRIAL, SINGLE>(plan, args, d_params, s);
+    case 2048: return launch_tiled_instance<E, TPP, 2048, VIRIAL, SINGLE>(plan, args, d_params, s);
+    case 4096: return launch_tiled_instance<E, TPP, 4096, VIRIAL, SINGLE>(plan, args, d_params, s);
+    default: return AZP_ERROR_INVALID_ARGUMENT;
+        }
+    }
+
+template<class E, bool VIRIAL, bool SINGLE>
+int launch_tiled_tpp(const PairPlan& plan, const azp_pair_args& args, const typename E::Params* d_params, hipStream_t s)
+    {
+    switch (plan.tpp)
+        {
+    case 1: return launch_tiled_cap<E, 1, VIRIAL, SINGLE>(plan, args, d_params, s);
+    case 2: return launch_tiled_cap<E, 2, VIRIAL, SINGLE>(plan, args, d_params, s);
+    case 4: return launch_tiled_cap<E, 4, VIRIAL, SINGLE>(plan, args, d_params, s);
+    default: return AZP_ERROR_INVALID_ARGUMENT;
+        }
+    }
+
+// Entry: use the plan when it is valid for these arguments, else the generic kernel.
+template<class E>
+int launch_pair_planned(azp_pair_plan* plan_, const azp_pair_args* args, const typename E::Params* d_params, void* stream)
+    {
+    if (!plan_)
+        return AZP_ERROR_INVALID_ARGUMENT;
+    const PairPlan& plan = *reinterpret_cast<const PairPlan*>(plan_);
+    const int bad = validate_pair_args(args, d_params);
+    if (bad < 0) return bad;
+    if (bad > 0) return AZP_SUCCESS;
+    // a plan compiled from a different list is a caller bug, not a fallback case
+    if (plan.builds == 0 || plan.N != args->N || plan.nlist_ptr != args->d_nlist || plan.head_ptr != args->d_head_list)
+        return AZP_ERROR_INVALID_ARGUMENT;
+    if (!plan.valid)
+        return launch_pair<E>(args, d_params, stream);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool single = (args->ntypes == 1);
+    if (args->compute_virial)
+        return single ? launch_tiled_tpp<E, true, true>(plan, *args, d_params, s)
+                      : launch_tiled_tpp<E, true, false>(plan, *args, d_params, s);
+    return single ? launch_tiled_tpp<E, false, true>(plan, *args, d_params, s)
+                  : launch_tiled_tpp<E, false, false>(plan, *args, d_params, s);
+    }
+
+} // namespace azp

@@ -219,6 +219,7 @@ def bench_main(args, rank, world, local_rank):
     pot.params[("A", "A")] = cfg["params"]
     pot.threads_per_particle = args.tpp
     pot.block_size = args.block_size
+    pot.use_plan = not args.no_plan
     sim.operations.integrator = azp.Integrator(dt=0.005, forces=[pot])
     halo.exchange(state.pos)
     sim.run(0)
@@ -280,6 +281,7 @@ def bench_main(args, rank, world, local_rank):
                 "per_rank": [dict(N_local=int(g[0]), n_ghost=int(g[1])) for g in gathered],
                 "halo_bytes_sent_per_step_rank0": halo.bytes_sent_per_step,
                 "launch": azp._lib.last_launch(),
+                "tile_plan": pot.plan_info,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

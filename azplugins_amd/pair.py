@@ -23,6 +23,7 @@ class Pair(Force):
 
     _cpp_class_name = None          # name the reference registers in _azplugins
     _entry = None                   # libazp entry point
+    _planned_entry = None           # tile-plan entry point (isotropic pairs)
     _schema = {}
     _param_doubles = 4              # size of the raw param struct in doubles
     _accepted_modes = ("none", "shift", "xplor")
@@ -38,6 +39,9 @@ class Pair(Force):
         self.r_on = ScalarTypeParameter("r_on", default_r_on, self._mark_dirty)
         self.threads_per_particle = 0   # 0 = library heuristic (HOOMD autotunes this)
         self.block_size = 0
+        self.use_plan = True            # LDS-staged tile kernel when the neighbor list can be tiled
+        self._plan = None
+        self._plan_builds = None
         self._tables = None
         nlist._add_consumer(self)
 
@@ -149,8 +153,23 @@ class Pair(Force):
 
     def _launch(self, stream, timestep):
         a = self._pair_args()
+        if self.use_plan and self._planned_entry is not None:
+            if self._plan is None:
+                self._plan = _lib.PairPlan()
+            key = (id(self.nlist), self.nlist.num_builds, self.threads_per_particle)
+            if self._plan_builds != key:
+                # recompile the plan only when the neighbor list was rebuilt
+                self._plan.build(a, stream)
+                self._plan_builds = key
+            fn = getattr(_lib.lib(), self._planned_entry)
+            _lib.check(fn(self._plan.handle, C.byref(a), self._tables["params"].data_ptr(), stream), self._planned_entry)
+            return
         fn = getattr(_lib.lib(), self._entry)
         _lib.check(fn(C.byref(a), self._tables["params"].data_ptr(), stream), self._entry)
+
+    @property
+    def plan_info(self):
+        return self._plan.info() if self._plan is not None else None
 
 
 def _d(x):
@@ -162,6 +181,7 @@ class Colloid(Pair):
 
     _cpp_class_name = "PotentialPairColloid"
     _entry = "azp_pair_forces_colloid"
+    _planned_entry = "azp_pair_forces_planned_colloid"
     _schema = dict(A=float, a_1=float, a_2=float, sigma=float)
 
     def _pack(self, d):
@@ -180,6 +200,7 @@ class ExpandedYukawa(Pair):
 
     _cpp_class_name = "PotentialPairExpandedYukawa"
     _entry = "azp_pair_forces_expanded_yukawa"
+    _planned_entry = "azp_pair_forces_planned_expanded_yukawa"
     _schema = dict(epsilon=float, kappa=float, delta=float)
 
     def _pack(self, d):
@@ -194,6 +215,7 @@ class Hertz(Pair):
 
     _cpp_class_name = "PotentialPairHertz"
     _entry = "azp_pair_forces_hertz"
+    _planned_entry = "azp_pair_forces_planned_hertz"
     _schema = dict(epsilon=float)
     _param_doubles = 1
 
@@ -209,6 +231,7 @@ class PerturbedLennardJones(Pair):
 
     _cpp_class_name = "PotentialPairPerturbedLennardJones"
     _entry = "azp_pair_forces_perturbed_lennard_jones"
+    _planned_entry = "azp_pair_forces_planned_perturbed_lennard_jones"
     _schema = dict(epsilon=float, sigma=float, attraction_scale_factor=float)
 
     def _pack(self, d):
@@ -269,6 +292,7 @@ class DPDConservativeGeneralWeight(Pair):
 
     _cpp_class_name = "PotentialPairConservativeGeneralWeight"
     _entry = "azp_pair_forces_dpd_conservative"
+    _planned_entry = "azp_pair_forces_planned_dpd_conservative"
     _schema = dict(A=float, gamma=float, s=float)
     _accepted_modes = ("none",)
 

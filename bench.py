@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--block-size", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="none", choices=["none", "shift", "xplor"])
+    ap.add_argument("--no-plan", action="store_true", help="generic kernel only (no LDS-staged tile plan)")
     args = ap.parse_args()
 
     import torch
@@ -121,8 +122,9 @@ def main():
     pot.params[("A", "A")] = cfg["params"]
     pot.threads_per_particle = args.tpp
     pot.block_size = args.block_size
+    pot.use_plan = not args.no_plan
     sim.operations.integrator = azp.Integrator(dt=0.005, forces=[pot])
-    sim.run(0)  # attaches, builds the neighbor list on the GPU, first force evaluation
+    sim.run(0)  # attaches, builds the neighbor list (and the tile plan) on the GPU, first force evaluation
     mean_neigh = nl.size / N
 
     for _ in range(args.warmup):
@@ -164,6 +166,7 @@ def main():
             "N": N,
             "mean_neighbors": mean_neigh,
             "launch": launch,
+            "tile_plan": pot.plan_info,
             "parallelism": "1 GPU",
         },
         "roofline": {
@@ -174,7 +177,7 @@ def main():
             "frac": achieved / HBM_PEAK_GBS,
             "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
             "traffic": None,
-            "kernel": "azp::pair_forces_kernel<EvalPLJ>",
+            "kernel": "azp::pair_forces_tiled_kernel<EvalPLJ>" if (pot.plan_info or {}).get("valid") else "azp::pair_forces_kernel<EvalPLJ>",
             "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_particle": b_alg,
         },

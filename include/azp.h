@@ -145,6 +145,53 @@ int azp_pair_forces_colloid(const azp_pair_args* args, const azp_colloid_params*
 /* PotentialPairConservativeGeneralWeight (src/export_PotentialPairDPDThermo.cc.inc:33-35) */
 int azp_pair_forces_dpd_conservative(const azp_pair_args* args, const azp_dpd_params* d_params, void* stream);
 
+/* ---- tile plan: compiled neighbor list for the LDS-staged pair kernel ----
+ * The generic azp_pair_forces_* kernels gather every neighbor position through
+ * L1/L2. When the particle order is spatially sorted (HOOMD's SFC sorter), a
+ * plan lets the kernels stage each tile's neighbor positions once in LDS and
+ * address them with 16-bit tile-local indices (see csrc/pair_plan.hpp).
+ * Build the plan whenever the neighbor list was rebuilt (HOOMD:
+ * NeighborList::getNumUpdates() changed) -- it synchronises the stream and may
+ * (re)allocate device workspace owned by the plan -- then call the *_planned
+ * entry points every step. If the list cannot be tiled (a tile's neighbor set
+ * exceeds 4095 particles, e.g. unsorted particle order) the plan is marked
+ * invalid and the planned entry points run the generic kernel instead. Tiles
+ * that are wide compared with the box, triclinic boxes, or calls without the
+ * r_list_max hint re-apply the minimum image per pair (slower, still exact).
+ * Results agree with the generic kernel to rounding. */
+typedef struct azp_pair_plan azp_pair_plan; /* opaque */
+
+typedef struct azp_pair_plan_info
+    {
+    int32_t valid;
+    int32_t invalid_reason;      /* 0 none, 2: a tile lists more than 4095 distinct neighbors */
+    uint32_t threads_per_particle;
+    uint32_t tile_size;          /* particles per tile (workgroup) */
+    uint32_t lds_slots;          /* staged-position capacity the kernel is instantiated for */
+    uint32_t n_tiles;
+    uint32_t max_stage;          /* largest staged set over all tiles */
+    uint32_t _pad;
+    uint64_t total_stage;        /* sum of staged-set sizes */
+    uint64_t compiled_bytes;     /* size of the compiled 16-bit list */
+    uint64_t builds;
+    } azp_pair_plan_info;
+
+int azp_pair_plan_create(azp_pair_plan** out);
+void azp_pair_plan_destroy(azp_pair_plan* plan);
+int azp_pair_plan_build(azp_pair_plan* plan, const azp_pair_args* args, void* stream);
+int azp_pair_plan_query(const azp_pair_plan* plan, azp_pair_plan_info* info);
+
+int azp_pair_forces_planned_perturbed_lennard_jones(azp_pair_plan* plan, const azp_pair_args* args,
+                                                    const azp_plj_params* d_params, void* stream);
+int azp_pair_forces_planned_hertz(azp_pair_plan* plan, const azp_pair_args* args, const azp_hertz_params* d_params,
+                                  void* stream);
+int azp_pair_forces_planned_expanded_yukawa(azp_pair_plan* plan, const azp_pair_args* args,
+                                            const azp_yukawa_params* d_params, void* stream);
+int azp_pair_forces_planned_colloid(azp_pair_plan* plan, const azp_pair_args* args, const azp_colloid_params* d_params,
+                                    void* stream);
+int azp_pair_forces_planned_dpd_conservative(azp_pair_plan* plan, const azp_pair_args* args,
+                                             const azp_dpd_params* d_params, void* stream);
+
 /* Mirrors hoomd::md::kernel::dpd_pair_args_t. */
 typedef struct azp_dpd_args
     {

@@ -84,9 +84,21 @@ def _finish(t, virial):
 
 
 def gpu_pair_forces(name, pos, box, nl, params, r_cut, r_on=0.0, mode="none", ntypes=1, N=None, virial=False, tpp=0,
-                    block_size=0, r_list_max=0.0):
+                    block_size=0, r_list_max=0.0, planned=False, plan_info=None):
+    """planned=True: build a tile plan from the list and use the *_planned entry
+    point; plan_info (a dict) receives azp_pair_plan_query's answer."""
     a, t = gpu_pair_args(pos, box, nl, ntypes, r_cut, r_on, mode, virial, N, tpp, block_size, r_list_max)
     p = _dev(np.atleast_2d(params).astype(np.float64))
+    if planned:
+        plan = _lib.PairPlan()
+        plan.build(a, _stream())
+        if plan_info is not None:
+            plan_info.update(plan.info())
+        entry = ENTRY[name].replace("azp_pair_forces_", "azp_pair_forces_planned_")
+        _lib.check(getattr(_lib.lib(), entry)(plan.handle, C.byref(a), p.data_ptr(), _stream()), entry)
+        out = _finish(t, virial)
+        del plan
+        return out
     fn = getattr(_lib.lib(), ENTRY[name])
     _lib.check(fn(C.byref(a), p.data_ptr(), _stream()), ENTRY[name])
     return _finish(t, virial)

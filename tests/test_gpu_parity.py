@@ -321,3 +321,142 @@ def test_plj_c2_full_size(oracle):
     assert np.abs(f_gpu[:, :3].sum(axis=0)).max() < 1e-9 * np.abs(f_gpu[:, :3]).max() * np.sqrt(len(f_gpu))
     f_again = H.gpu_pair_forces("PerturbedLennardJones", pos, (cfg["L"],), nl, params, 3.0, mode="shift", r_list_max=3.4)
     assert np.array_equal(f_again, f_gpu)
+
+
+# ---------------------------------------------------------------------------
+# tile-plan (LDS-staged) kernels: same observables, same tolerance
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["PerturbedLennardJones", "Hertz", "ExpandedYukawa", "Colloid", "DPDConservative"])
+@pytest.mark.parametrize("T", [1, 3])
+@pytest.mark.parametrize("mode", ["none", "shift", "xplor"])
+def test_planned_pair_parity(oracle, name, T, mode):
+    a = 1.1 if name != "Colloid" else 1.6
+    pos, L, typeid = H.lattice_config(20, a, 0.1 * a, seed=31, ntypes=T)
+    box = oracle.make_box(L)
+    r_cut = np.full((T, T), 2.5 if name != "Colloid" else 3.2)
+    if T > 1:
+        r_cut[0, 1] = r_cut[1, 0] = r_cut[0, 0] - 0.3
+    r_on = 0.8 * r_cut
+    params = _params_table(oracle, name, T)
+    nl = oracle.build_nlist(pos, box, r_cut + 0.3, ntypes=T)
+    f_ref, v_ref = oracle.pair_forces(name, pos, box, nl, params, r_cut, r_on, mode, ntypes=T, virial=True, nthreads=8)
+    info = {}
+    rl = float(r_cut.max()) + 0.3
+    f_gpu, v_gpu = H.gpu_pair_forces(name, pos, (L,), nl, params, r_cut, r_on, mode, ntypes=T, virial=True, planned=True,
+                                     plan_info=info, r_list_max=rl)
+    assert info["valid"] == 1, info
+    assert_close(f_gpu[:, :3], f_ref[:, :3], what="force")
+    assert_close(f_gpu[:, 3], f_ref[:, 3], what="energy")
+    assert_close(v_gpu, v_ref, what="virial")
+    assert_per_particle(f_gpu, f_ref)
+    f2 = H.gpu_pair_forces(name, pos, (L,), nl, params, r_cut, r_on, mode, ntypes=T, planned=True, r_list_max=rl)
+    assert np.array_equal(f2, f_gpu)
+    # without the hint every pair is re-imaged: same forces to rounding
+    f3 = H.gpu_pair_forces(name, pos, (L,), nl, params, r_cut, r_on, mode, ntypes=T, planned=True)
+    assert_close(f3, f_gpu, tol=1e-12)
+
+
+@pytest.mark.parametrize("tpp", [1, 2, 4])
+def test_planned_launch_shapes(oracle, tpp):
+    """Every lanes-per-particle variant of the tile kernel, N not a multiple of
+    the tile size, rows of very different lengths (a slab of vacuum)."""
+    cfg = syn.config_plj_sc(22)
+    keep = ~((cfg["xyz"][:, 2] > 2.0) & (cfg["xyz"][:, 2] < 6.0))
+    pos = syn.pos4(cfg["xyz"][keep][:-7])
+    L = cfg["L"]
+    box = oracle.make_box(L)
+    params = oracle.pack_pair_params("PerturbedLennardJones", cfg["params"])
+    nl = oracle.build_nlist(pos, box, 3.4)
+    assert nl[0].min() < 0.7 * nl[0].max()
+    f_ref = oracle.pair_forces("PerturbedLennardJones", pos, box, nl, params, 3.0, mode="shift", nthreads=8)
+    info = {}
+    f_gpu = H.gpu_pair_forces("PerturbedLennardJones", pos, (L,), nl, params, 3.0, mode="shift", tpp=tpp, planned=True,
+                              plan_info=info, r_list_max=3.4)
+    assert info["valid"] == 1 and info["threads_per_particle"] == tpp and info["tile_size"] == 256 // tpp
+    assert_close(f_gpu, f_ref)
+    assert_per_particle(f_gpu, f_ref)
+
+
+def test_planned_small_box_and_unsorted_particles(oracle):
+    """A box narrower than a tile plus its halo cannot rely on one staged image
+    per neighbor: those tiles re-apply the minimum image per pair. Unsorted
+    particles make a tile's neighbor set exceed the LDS budget: the plan reports
+    invalid and the planned entry point runs the generic kernel. Same answer."""
+    cfg = syn.config_plj_sc(9)
+    pos = syn.pos4(cfg["xyz"])
+    box = oracle.make_box(cfg["L"])
+    params = oracle.pack_pair_params("PerturbedLennardJones", cfg["params"])
+    nl = oracle.build_nlist(pos, box, 3.4)
+    info = {}
+    f_gpu = H.gpu_pair_forces("PerturbedLennardJones", pos, (cfg["L"],), nl, params, 3.0, planned=True, plan_info=info,
+                              r_list_max=3.4)
+    assert info["valid"] == 1
+    assert_close(f_gpu, oracle.pair_forces("PerturbedLennardJones", pos, box, nl, params, 3.0))
+    # triclinic box through the plan
+    tilt = (0.2, -0.1, 0.15)
+    cfg10 = syn.config_plj_sc(10)
+    pos10 = syn.pos4(cfg10["xyz"])
+    nl10 = oracle.build_nlist(pos10, oracle.make_box(cfg10["L"]), 4.5)
+    f_ref = oracle.pair_forces("PerturbedLennardJones", pos10, oracle.make_box(cfg10["L"], tilt=tilt), nl10, params, 2.0)
+    f_gpu = H.gpu_pair_forces("PerturbedLennardJones", pos10, (cfg10["L"], tilt), nl10, params, 2.0, planned=True,
+                              r_list_max=4.5)
+    assert_close(f_gpu, f_ref)
+    # unsorted particle order => invalid plan, generic kernel, still correct
+    cfg = syn.config_plj_sc(20)
+    perm = np.argsort(syn.hash64(99, np.arange(8000, dtype=np.uint64), 0))
+    pos = syn.pos4(cfg["xyz"][perm])
+    box = oracle.make_box(cfg["L"])
+    nl = oracle.build_nlist(pos, box, 3.4)
+    info = {}
+    f_gpu = H.gpu_pair_forces("PerturbedLennardJones", pos, (cfg["L"],), nl, params, 3.0, planned=True, plan_info=info)
+    assert info["valid"] == 0 and info["invalid_reason"] == 2
+    assert_close(f_gpu, oracle.pair_forces("PerturbedLennardJones", pos, box, nl, params, 3.0, nthreads=8))
+
+
+def test_planned_ghosts_nonperiodic_and_stale_plan(oracle):
+    import ctypes as C
+
+    from azplugins_amd import _lib
+
+    cfg = syn.config_plj_sc(20)
+    xyz = cfg["xyz"]
+    L = cfg["L"]
+    order = np.argsort(xyz[:, 0] > 0.0, kind="stable")
+    pos = syn.pos4(xyz[order])
+    N = int((xyz[:, 0] <= 0.0).sum())
+    box_o = oracle.make_box(L, periodic=(0, 1, 1))
+    params = oracle.pack_pair_params("PerturbedLennardJones", cfg["params"])
+    nl = oracle.build_nlist(pos, box_o, 2.9, N=N)
+    f_ref = oracle.pair_forces("PerturbedLennardJones", pos, box_o, nl, params, 2.5, N=N)
+    info = {}
+    f_gpu = H.gpu_pair_forces("PerturbedLennardJones", pos, (L, (0, 0, 0), (0, 1, 1)), nl, params, 2.5, N=N, planned=True,
+                              plan_info=info, r_list_max=2.9)
+    assert info["valid"] == 1
+    assert_close(f_gpu, f_ref)
+    # a plan compiled for another list is rejected, not silently used
+    a, t = H.gpu_pair_args(pos, (L, (0, 0, 0), (0, 1, 1)), nl, 1, 2.5, 0.0, "none", False, N)
+    plan = _lib.PairPlan()
+    plan.build(a, H._stream())
+    a2, t2 = H.gpu_pair_args(pos, (L, (0, 0, 0), (0, 1, 1)), nl, 1, 2.5, 0.0, "none", False, N)
+    p = H._dev(np.atleast_2d(params))
+    rc = _lib.lib().azp_pair_forces_planned_perturbed_lennard_jones(plan.handle, C.byref(a2), p.data_ptr(), H._stream())
+    assert rc == -1
+
+
+def test_planned_plj_c2_full_size(oracle):
+    """configs[1] at full size through the tile plan."""
+    cfg = syn.config_plj_sc(64)
+    pos = syn.pos4(cfg["xyz"])
+    box = oracle.make_box(cfg["L"])
+    params = oracle.pack_pair_params("PerturbedLennardJones", cfg["params"])
+    nl = oracle.build_nlist(pos, box, 3.4)
+    f_ref = oracle.pair_forces("PerturbedLennardJones", pos, box, nl, params, 3.0, mode="shift", nthreads=16)
+    info = {}
+    f_gpu = H.gpu_pair_forces("PerturbedLennardJones", pos, (cfg["L"],), nl, params, 3.0, mode="shift", planned=True,
+                              plan_info=info, r_list_max=3.4)
+    assert info["valid"] == 1
+    assert_close(f_gpu, f_ref)
+    assert_per_particle(f_gpu, f_ref)
+    f_again = H.gpu_pair_forces("PerturbedLennardJones", pos, (cfg["L"],), nl, params, 3.0, mode="shift", planned=True,
+                                r_list_max=3.4)
+    assert np.array_equal(f_again, f_gpu)
