@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libazp.so")
+LIB_PATH = os.environ.get("AZP_LIB_PATH", os.path.join(_HERE, "libazp.so"))  # env override: kernel experiments only
 CSRC = os.path.join(_HERE, "csrc")
 
 

@@ -2,16 +2,17 @@
 // neighbor list, on the GPU, and owns its device workspace.
 //
 // Two passes over the list, both one workgroup per tile:
-//   count: LDS hash-set of the tile's neighbor indices -> number of staged
-//          particles (a tile whose neighbor set exceeds 4095 particles -- e.g.
-//          unsorted particle order -- invalidates the plan) and per-slice chunk
-//          counts
-//   fill : same hash-set, compacted and bitonic-sorted in LDS -> stage_idx; then
-//          every row entry is translated (binary search in LDS) to a u16 byte
-//          offset and written as 16-byte chunks in the force kernel's own
-//          lane order (coalesced 1 KiB stores).
-// Host-side exclusive scans sit between the passes (plan build is a sync point,
-// like HOOMD's own neighbor-list overflow check).
+//   chunks: per-slice chunk counts from the row lengths (tiny kernel), host scan
+//   build : one workgroup per tile. LDS hash-set of the tile's neighbor indices,
+//           compacted and bitonic-sorted in LDS -> stage_idx (a tile whose neighbor
+//           set exceeds PLAN_MAX_STAGE particles -- e.g. unsorted particle order --
+//           invalidates the plan); the staged positions are loaded into LDS; every
+//           row entry is translated (hash lookup) to a u16 byte offset, classified
+//           near / far (inside the cutoff now or only in the Verlet buffer), and the
+//           row is written near-first as 16-byte chunks in the force kernel's own
+//           lane order.
+// The host-side scan makes plan build a sync point, like HOOMD's own
+// neighbor-list overflow check.
 #include <algorithm>
 #include <vector>
 
@@ -26,8 +27,9 @@ struct PlanKArgs
     const uint32_t* n_neigh;
     const uint32_t* nlist;
     const uint64_t* head_list;
+    const double* rcutsq;
     uint32_t* tile_nstage;
-    const uint64_t* tile_head;
+    uint64_t* tile_head;
     uint32_t* stage_idx;
     uint32_t* slice_K;
     const uint64_t* slice_head;
@@ -35,86 +37,135 @@ struct PlanKArgs
     uint32_t* flags;
     BoxDev box;
     uint32_t N;
+    uint32_t ntypes;
+    uint32_t stage_stride; // stage_idx entries reserved per tile
     };
 
-__device__ __forceinline__ uint32_t plan_hash(uint32_t j) { return (j * 2654435761u) >> 19; } // 13 bits
+template<uint32_t HC> __device__ __forceinline__ uint32_t plan_hash(uint32_t j)
+    {
+    return (j * 2654435761u) >> (HC == 8192 ? 19 : 20); // 13 or 12 bits
+    }
 
+// Insert j into the open-addressing hash set; returns false if the table is full.
+// Neighboring particles list mostly the same neighbors, so ~96 % of the inserts
+// find their key already present: probe with a plain read first and fall back to
+// the (slower) atomic only on an empty slot.
+template<uint32_t HC> __device__ __forceinline__ bool plan_insert(uint32_t* table, uint32_t j)
+    {
+    uint32_t h = plan_hash<HC>(j);
+    for (uint32_t probe = 0; probe < HC; ++probe)
+        {
+        uint32_t cur = table[h];
+        if (cur == PLAN_EMPTY)
+            cur = atomicCAS(&table[h], PLAN_EMPTY, j);
+        if (cur == PLAN_EMPTY || cur == j)
+            return true;
+        h = (h + 1) & (HC - 1);
+        }
+    return false;
+    }
 
-template<int TPP, bool FILL> __global__ void __launch_bounds__(256) plan_build_kernel(const PlanKArgs a)
+// Position of key j in the table (j is known to be present).
+template<uint32_t HC> __device__ __forceinline__ uint32_t plan_find(const uint32_t* table, uint32_t j)
+    {
+    uint32_t h = plan_hash<HC>(j);
+    while (table[h] != j)
+        h = (h + 1) & (HC - 1);
+    return h;
+    }
+
+// Chunk count per slice: K = ceil(max row length in the slice / (8 * TPP)).
+template<int TPP> __global__ void __launch_bounds__(256) plan_chunks_kernel(const PlanKArgs a)
+    {
+    constexpr int PW = 64 / TPP;
+    const uint32_t slice = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t i = slice * PW + lane;
+    uint32_t nrow = (lane < PW && i < a.N) ? a.n_neigh[i] : 0u;
+    for (int off = 32; off > 0; off >>= 1)
+        nrow = max(nrow, (uint32_t)__shfl_xor((int)nrow, off, 64));
+    if (lane == 0)
+        {
+        a.slice_K[slice] = (nrow + 8 * TPP - 1) / (8 * TPP);
+        if (nrow + 8 * TPP > PLAN_ROWBUF)
+            atomicOr(&a.flags[1], 1u); // row too long for the builder's row buffer
+        }
+    }
+
+// One workgroup per tile: dedup the tile's neighbor indices (LDS hash set), sort
+// them (bitonic, LDS) into the stage list, then compile every row.
+//
+// Compiled row order: entries that are inside the cutoff at build time come
+// first ("near"), the Verlet-buffer entries after them ("far"), padding last; the
+// original order is kept inside each part. The force kernel tests each half chunk
+// exactly and skips the arithmetic when no lane of the wave has a pair in range --
+// which is what the tail of every row looks like -- so the ordering is purely a
+// performance hint.
+constexpr int PLAN_BUILD_THREADS = 512; // 8 waves per tile: more independent dependency chains in flight
+constexpr int PLAN_BUILD_WAVES = PLAN_BUILD_THREADS / 64;
+
+template<int TPP, uint32_t HC>
+__global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const PlanKArgs a)
     {
     constexpr int TB = 256 / TPP; // particles per tile
-    constexpr int PW = 64 / TPP;  // particles per wave (slice)
-    __shared__ uint32_t table[PLAN_HASH_CAP];
-    __shared__ uint32_t list[FILL ? 4096 : 1];
+    constexpr int PW = 64 / TPP;  // particles per slice (one force-kernel wave)
+    constexpr int ITERS = PLAN_ROWBUF / 64;
+    constexpr int NT = PLAN_BUILD_THREADS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    uint32_t* table = reinterpret_cast<uint32_t*>(s_raw);          // HC keys
+    uint16_t* slot_of = reinterpret_cast<uint16_t*>(table + HC);   // HC
+    uint16_t* w_rowbuf = slot_of + HC;                             // PLAN_BUILD_WAVES x PLAN_ROWBUF
+    // list[4096] (sort scratch) and the staged positions (stage_stride slots) share
+    // one region: the list is dead once slots and positions are published
+    uint32_t* list = reinterpret_cast<uint32_t*>(w_rowbuf + PLAN_BUILD_WAVES * PLAN_ROWBUF);
+    // staged positions relative to the tile's reference particle, as float4
+    // (x, y, z, type): they only feed the near/far ordering hint, never a force
+    float4* s_p = reinterpret_cast<float4*>(list);
     __shared__ uint32_t s_n, s_overflow;
+    __shared__ double s_rcutsq[64]; // up to 8 types cached; more types read the global table
 
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = tid >> 6, lane = tid & 63;
     const uint32_t tile = blockIdx.x;
     const uint32_t first = tile * TB;
     const uint32_t count = min((uint32_t)TB, a.N - first);
+    const bool rc_cached = a.ntypes <= 8;
 
-    for (uint32_t t = tid; t < PLAN_HASH_CAP; t += 256)
+    for (uint32_t t = tid; t < HC; t += NT)
         table[t] = PLAN_EMPTY;
+    for (uint32_t t = tid; t < 4096; t += NT)
+        list[t] = PLAN_EMPTY;
     if (tid == 0) { s_n = 0; s_overflow = 0; }
+    if (rc_cached && tid < a.ntypes * a.ntypes)
+        s_rcutsq[tid] = a.rcutsq[tid];
     __syncthreads();
 
-    // ---- hash-set of all neighbor indices of the tile ----
-    for (uint32_t p = wave; p < count; p += 4)
+    // ---- hash-set of all neighbor indices of the tile: every wave takes rows
+    // round-robin and issues all of a row's index loads before probing ----
+    for (uint32_t p = wave; p < count; p += PLAN_BUILD_WAVES)
         {
         const uint32_t i = first + p;
         const uint32_t n = a.n_neigh[i];
         const uint32_t* row = a.nlist + a.head_list[i];
-        for (uint32_t k = lane; k < n; k += 64)
+        uint32_t jj[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it)
             {
-            const uint32_t j = row[k];
-            uint32_t h = plan_hash(j);
-            bool done = false;
-            for (uint32_t probe = 0; probe < PLAN_HASH_CAP && !done; ++probe)
-                {
-                const uint32_t old = atomicCAS(&table[h], PLAN_EMPTY, j);
-                if (old == PLAN_EMPTY || old == j)
-                    done = true;
-                else
-                    h = (h + 1) & (PLAN_HASH_CAP - 1);
-                }
-            if (!done)
+            const uint32_t k = (uint32_t)it * 64u + lane;
+            jj[it] = (k < n) ? row[k] : PLAN_EMPTY;
+            }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it)
+            if (jj[it] != PLAN_EMPTY && !plan_insert<HC>(table, jj[it]))
                 s_overflow = 1;
-            }
         }
     __syncthreads();
 
-    if (!FILL)
-        {
-        // ---- count uniques ----
-        uint32_t mine = 0;
-        for (uint32_t t = tid; t < PLAN_HASH_CAP; t += 256)
-            mine += (table[t] != PLAN_EMPTY);
-        atomicAdd(&s_n, mine);
-        // per-slice chunk count: K = ceil(max row length / (8 * TPP))
-        uint32_t nrow = 0;
-        if (lane < PW && wave * PW + lane < count)
-            nrow = a.n_neigh[first + wave * PW + lane];
-        for (int off = 32; off > 0; off >>= 1)
-            nrow = max(nrow, (uint32_t)__shfl_xor((int)nrow, off, 64));
-        if (lane == 0)
-            a.slice_K[tile * 4 + wave] = (nrow + 8 * TPP - 1) / (8 * TPP);
-        __syncthreads();
-        if (tid == 0)
-            {
-            a.tile_nstage[tile] = s_n;
-            if (s_overflow || s_n > PLAN_MAX_STAGE)
-                atomicOr(&a.flags[1], 1u);
-            atomicMax(&a.flags[2], s_n);
-            }
-        return;
-        }
-
-    // ---- FILL: compact, sort, publish the stage list ----
-    for (uint32_t t = tid; t < 4096; t += 256)
-        list[t] = PLAN_EMPTY;
-    __syncthreads();
-    for (uint32_t t = tid; t < PLAN_HASH_CAP; t += 256)
+#if defined(PLAN_ABLATE) && PLAN_ABLATE == 1
+    return;
+#endif
+    // ---- compact + sort ----
+    for (uint32_t t = tid; t < HC; t += NT)
         {
         const uint32_t j = table[t];
         if (j != PLAN_EMPTY)
@@ -125,67 +176,183 @@ template<int TPP, bool FILL> __global__ void __launch_bounds__(256) plan_build_k
             }
         }
     __syncthreads();
-    const uint32_t n_stage = min(s_n, (uint32_t)PLAN_MAX_STAGE);
+    const bool bad = s_overflow || s_n > PLAN_MAX_STAGE || s_n > a.stage_stride || s_n > HC / 2;
+    const uint32_t n_stage = bad ? 0u : s_n;
+    if (tid == 0)
+        {
+        a.tile_nstage[tile] = n_stage;
+        a.tile_head[tile] = (uint64_t)tile * a.stage_stride;
+        if (bad)
+            atomicOr(&a.flags[1], 1u);
+        atomicMax(&a.flags[2], s_n);
+        }
+    if (bad)
+        return; // the plan is invalid; nothing downstream will read this tile
     uint32_t npow = 64;
     while (npow < n_stage) npow <<= 1;
-    // bitonic sort of list[0..npow) (padding = 0xFFFFFFFF sorts to the end)
-    for (uint32_t size = 2; size <= npow; size <<= 1)
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1)
+    // bitonic sort of list[0..npow) (padding = 0xFFFFFFFF sorts to the end). A wave's
+    // compare-exchange pairs t in [64 w, 64 w + 63] (+ multiples of NT) touch only
+    // the 128-element block 128 w .. 128 w + 127 whenever stride <= 64, so those
+    // stages need no workgroup barrier -- only the stride >= 128 stages do.
+    auto cmpswap = [&](uint32_t t, uint32_t size, uint32_t stride)
+        {
+        const uint32_t lo = 2 * t - (t & (stride - 1));
+        const uint32_t hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const uint32_t x = list[lo], y = list[hi];
+        if ((x > y) == up)
             {
-            for (uint32_t t = tid; t < (npow >> 1); t += 256)
-                {
-                const uint32_t lo = 2 * t - (t & (stride - 1));
-                const uint32_t hi = lo + stride;
-                const bool up = ((lo & size) == 0);
-                const uint32_t x = list[lo], y = list[hi];
-                if ((x > y) == up)
-                    {
-                    list[lo] = y;
-                    list[hi] = x;
-                    }
-                }
+            list[lo] = y;
+            list[hi] = x;
+            }
+        };
+    for (uint32_t size = 2; size <= npow; size <<= 1)
+        {
+        uint32_t stride = size >> 1;
+        for (; stride >= 128; stride >>= 1)
+            {
+            for (uint32_t t = tid; t < (npow >> 1); t += NT)
+                cmpswap(t, size, stride);
             __syncthreads();
             }
-    uint32_t* stage = a.stage_idx + a.tile_head[tile];
-    for (uint32_t t = tid; t < n_stage; t += 256)
-        stage[t] = list[t];
-
-    // ---- translate rows into the force kernel's chunk order ----
-    const uint32_t pl = lane / TPP, sub = lane % TPP;
-    const uint32_t slice = tile * 4 + wave;
-    const uint32_t K = a.slice_K[slice];
-    uint4* out = a.cnl + (a.slice_head[slice] * 64ull);
-    const uint32_t pidx = wave * PW + pl;
-    uint32_t n = 0;
-    const uint32_t* row = a.nlist;
-    if (pidx < count)
-        {
-        n = a.n_neigh[first + pidx];
-        row = a.nlist + a.head_list[first + pidx];
-        }
-    for (uint32_t kk = 0; kk < K; ++kk)
-        {
-        const uint32_t base = (kk * TPP + sub) * 8;
-        uint32_t w[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
+        for (; stride > 0; stride >>= 1)
             {
-            const uint32_t k = base + e;
-            uint32_t off = 0;
-            if (k < n)
-                {
-                const uint32_t j = row[k];
-                uint32_t lo = 0, hi = n_stage;
-                while (lo < hi)
-                    {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (list[mid] < j) lo = mid + 1; else hi = mid;
-                    }
-                off = (lo + 1) * 8;
-                }
-            w[e >> 1] |= off << (16 * (e & 1));
+            for (uint32_t t = tid; t < (npow >> 1); t += NT)
+                cmpswap(t, size, stride);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // same-wave LDS ordering
             }
-        out[(uint64_t)kk * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+        __syncthreads();
+        }
+    // publish; remember each key's slot; stage positions relative to the tile's
+    // reference particle for the near/far classification. The positions overwrite
+    // the sort scratch, so every thread first pulls its keys into registers.
+    uint32_t* stage = a.stage_idx + (uint64_t)tile * a.stage_stride;
+    const double3 c = load_scalar3_of4(a.pos, first);
+    constexpr int SMAX = (PLAN_MAX_STAGE + NT) / NT;
+    float4 pp4[SMAX];
+#pragma unroll
+    for (int it = 0; it < SMAX; ++it)
+        {
+        const uint32_t t = (uint32_t)it * NT + tid;
+        pp4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < n_stage)
+            {
+            const uint32_t j = list[t];
+            stage[t] = j;
+            slot_of[plan_find<HC>(table, j)] = (uint16_t)t;
+            const double4 pj = load_scalar4(a.pos, j);
+            double dx = pj.x - c.x, dy = pj.y - c.y, dz = pj.z - c.z;
+            min_image(a.box, dx, dy, dz);
+            pp4[it] = make_float4((float)dx, (float)dy, (float)dz, __int_as_float(type_from_w(pj.w)));
+            }
+        }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < SMAX; ++it)
+        {
+        const uint32_t t = (uint32_t)it * NT + tid;
+        if (t < n_stage)
+            s_p[t] = pp4[it];
+        }
+    __syncthreads();
+
+#if defined(PLAN_ABLATE) && PLAN_ABLATE == 2
+    return;
+#endif
+    // ---- compile rows, one row per wave at a time (no block barriers from here on).
+    // Stable near/far partition with wave ballots: every lane classifies up to
+    // ITERS entries (k = lane, lane + 64, ...), the ballots give each entry its rank
+    // inside its part, and the u16 offsets land in the wave's row buffer.
+    uint16_t* rowbuf = w_rowbuf + wave * PLAN_ROWBUF;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (uint32_t p = wave; p < (uint32_t)TB; p += PLAN_BUILD_WAVES)
+        {
+        const uint32_t fwave = p / PW, pl = p % PW; // force-kernel wave (slice) and particle inside it
+        const uint32_t slice = tile * 4 + fwave;
+        const uint32_t K = a.slice_K[slice];
+        uint4* out = a.cnl + (a.slice_head[slice] * 64ull);
+        const uint32_t row_cap = K * TPP * 8u; // entries the slice's rectangle gives each particle
+        uint32_t n = 0;
+        const uint32_t* row = a.nlist;
+        float xi = 0.f, yi = 0.f, zi = 0.f;
+        uint32_t trow = 0;
+        if (p < count)
+            {
+            const uint32_t i = first + p;
+            n = a.n_neigh[i];
+            row = a.nlist + a.head_list[i];
+            const double4 pp = load_scalar4(a.pos, i);
+            double dxi = pp.x - c.x, dyi = pp.y - c.y, dzi = pp.z - c.z;
+            min_image(a.box, dxi, dyi, dzi);
+            xi = (float)dxi; yi = (float)dyi; zi = (float)dzi;
+            trow = (uint32_t)type_from_w(pp.w) * a.ntypes;
+            }
+        // all index loads of the row in flight together
+        uint32_t jj[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it)
+            {
+            const uint32_t k = (uint32_t)it * 64u + lane;
+            jj[it] = (k < n) ? row[k] : PLAN_EMPTY;
+            }
+        const uint32_t iters = (n + 63u) >> 6;
+        // pass A: translate + classify, count the near entries
+        uint32_t n_near = 0;
+        uint32_t enc[ITERS]; // (offset << 1) | near, 0 = no entry
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it)
+            {
+            enc[it] = 0;
+            if ((uint32_t)it < iters)
+                {
+                bool near = false;
+                if (jj[it] != PLAN_EMPTY)
+                    {
+                    const uint32_t sidx = slot_of[plan_find<HC>(table, jj[it])];
+                    const float4 q = s_p[sidx];
+                    double dx = xi - q.x, dy = yi - q.y, dz = zi - q.z;
+                    min_image(a.box, dx, dy, dz);
+                    const double rsq = dx * dx + dy * dy + dz * dz;
+                    const uint32_t tp = trow + (uint32_t)__float_as_int(q.w);
+                    near = rsq < (rc_cached ? s_rcutsq[tp] : a.rcutsq[tp]);
+                    enc[it] = (((sidx + 1u) * 8u) << 1) | (near ? 1u : 0u);
+                    }
+                n_near += (uint32_t)__popcll(__ballot(near));
+                }
+            }
+        // pass B: scatter into the row buffer, near part first
+        uint32_t base_near = 0, base_far = n_near;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it)
+            {
+            if ((uint32_t)it < iters)
+                {
+                const bool valid = enc[it] != 0;
+                const bool near = enc[it] & 1u;
+                const uint64_t m_near = __ballot(valid && near);
+                const uint64_t m_far = __ballot(valid && !near);
+                if (valid)
+                    {
+                    const uint32_t posn = near ? base_near + (uint32_t)__popcll(m_near & lt_mask)
+                                               : base_far + (uint32_t)__popcll(m_far & lt_mask);
+                    rowbuf[posn] = (uint16_t)(enc[it] >> 1);
+                    }
+                base_near += (uint32_t)__popcll(m_near);
+                base_far += (uint32_t)__popcll(m_far);
+                }
+            }
+#if defined(PLAN_ABLATE) && PLAN_ABLATE == 3
+        continue;
+#endif
+        // pad to the slice's rectangle with the dummy slot
+        for (uint32_t t = n + lane; t < row_cap; t += 64)
+            rowbuf[t] = 0;
+        __builtin_amdgcn_wave_barrier();
+        // 16-byte chunks in the force kernel's (iteration, lane) order
+        const uint4* rb4 = reinterpret_cast<const uint4*>(rowbuf);
+        for (uint32_t cidx = lane; cidx < K * TPP; cidx += 64)
+            out[(uint64_t)(cidx / TPP) * 64 + pl * TPP + (cidx % TPP)] = rb4[cidx];
+        __builtin_amdgcn_wave_barrier();
         }
     }
 
@@ -217,19 +384,47 @@ static void plan_free(PairPlan& p)
     p = PairPlan();
     }
 
-template<int TPP> static void launch_plan_kernel(bool fill, const PlanKArgs& k, uint32_t n_tiles, hipStream_t s)
+static size_t plan_lds_bytes(uint32_t hc, uint32_t stride)
     {
-    if (fill)
-        hipLaunchKernelGGL((plan_build_kernel<TPP, true>), dim3(n_tiles), dim3(256), 0, s, k);
-    else
-        hipLaunchKernelGGL((plan_build_kernel<TPP, false>), dim3(n_tiles), dim3(256), 0, s, k);
+    const size_t shared_region = std::max<size_t>(4096 * 4, (size_t)stride * 16);
+    return (size_t)hc * 4 + (size_t)hc * 2 + (size_t)PLAN_BUILD_WAVES * PLAN_ROWBUF * 2 + shared_region;
     }
 
-static void launch_plan(uint32_t tpp, bool fill, const PlanKArgs& k, uint32_t n_tiles, hipStream_t s)
+template<int TPP, uint32_t HC> static hipError_t launch_plan_build(const PlanKArgs& k, uint32_t n_tiles, hipStream_t s)
     {
-    if (tpp == 4) launch_plan_kernel<4>(fill, k, n_tiles, s);
-    else if (tpp == 2) launch_plan_kernel<2>(fill, k, n_tiles, s);
-    else launch_plan_kernel<1>(fill, k, n_tiles, s);
+    const size_t lds = plan_lds_bytes(HC, k.stage_stride);
+    auto kern = plan_build_kernel<TPP, HC>;
+    if (lds > 64 * 1024)
+        {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+        }
+    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(PLAN_BUILD_THREADS), lds, s, k);
+    return hipGetLastError();
+    }
+
+template<int TPP> static hipError_t launch_plan_kernels(int which, const PlanKArgs& k, uint32_t n_tiles, hipStream_t s)
+    {
+    if (which == 0)
+        hipLaunchKernelGGL((plan_chunks_kernel<TPP>), dim3(n_tiles), dim3(256), 0, s, k);
+    else
+        {
+        // a 4096-entry hash set (load factor <= 0.5) halves the LDS footprint and lets
+        // two build workgroups share a CU; large stage sets need the 8192-entry one
+        if (k.stage_stride <= 2048)
+            return launch_plan_build<TPP, 4096>(k, n_tiles, s);
+        return launch_plan_build<TPP, 8192>(k, n_tiles, s);
+        }
+    return hipGetLastError();
+    }
+
+static hipError_t launch_plan(uint32_t tpp, int which, const PlanKArgs& k, uint32_t n_tiles, hipStream_t s)
+    {
+    if (tpp == 4) return launch_plan_kernels<4>(which, k, n_tiles, s);
+    if (tpp == 2) return launch_plan_kernels<2>(which, k, n_tiles, s);
+    return launch_plan_kernels<1>(which, k, n_tiles, s);
     }
 
 #define AZP_HIP_TRY(expr)                      \
@@ -239,6 +434,10 @@ static void launch_plan(uint32_t tpp, bool fill, const PlanKArgs& k, uint32_t n_
         if (e_ != hipSuccess) return (int)e_;  \
         } while (0)
 
+// Build with a given tile size. Sequence: chunk counts (tiny kernel) -> host scan
+// of the slice heads (one small D2H/H2D round trip) -> one kernel per tile that
+// dedups, sorts and compiles. Stage lists live at a fixed stride per tile
+// (stage_stride entries), sized from the previous build and grown on overflow.
 static int plan_build_tpp(PairPlan& p, const azp_pair_args& args, uint32_t tpp, hipStream_t s)
     {
     p.valid = false;
@@ -262,6 +461,7 @@ static int plan_build_tpp(PairPlan& p, const azp_pair_args& args, uint32_t tpp, 
     k.n_neigh = args.d_n_neigh;
     k.nlist = args.d_nlist;
     k.head_list = args.d_head_list;
+    k.rcutsq = args.d_rcutsq;
     k.tile_nstage = p.d_tile_nstage;
     k.tile_head = p.d_tile_head;
     k.stage_idx = nullptr;
@@ -271,40 +471,56 @@ static int plan_build_tpp(PairPlan& p, const azp_pair_args& args, uint32_t tpp, 
     k.flags = p.d_flags;
     k.box = make_box_dev(args.box);
     k.N = args.N;
-    launch_plan(tpp, false, k, p.n_tiles, s);
-    AZP_HIP_TRY(hipGetLastError());
+    k.ntypes = args.ntypes;
+    k.stage_stride = 0;
+    AZP_HIP_TRY(launch_plan(tpp, 0, k, p.n_tiles, s));
 
-    std::vector<uint32_t> h_nstage(p.n_tiles), h_K(p.n_slices);
+    std::vector<uint32_t> h_K(p.n_slices);
     uint32_t h_flags[4];
-    AZP_HIP_TRY(hipMemcpyAsync(h_nstage.data(), p.d_tile_nstage, sizeof(uint32_t) * p.n_tiles, hipMemcpyDeviceToHost, s));
     AZP_HIP_TRY(hipMemcpyAsync(h_K.data(), p.d_slice_K, sizeof(uint32_t) * p.n_slices, hipMemcpyDeviceToHost, s));
     AZP_HIP_TRY(hipMemcpyAsync(h_flags, p.d_flags, sizeof(h_flags), hipMemcpyDeviceToHost, s));
     AZP_HIP_TRY(hipStreamSynchronize(s));
-    p.max_stage = h_flags[2];
     if (h_flags[1])
         {
         p.invalid_reason = 2;
         return AZP_SUCCESS;
         }
-    std::vector<uint64_t> h_thead(p.n_tiles), h_shead(p.n_slices);
+    std::vector<uint64_t> h_shead(p.n_slices);
     uint64_t acc = 0;
-    for (uint32_t t = 0; t < p.n_tiles; ++t) { h_thead[t] = acc; acc += h_nstage[t]; }
-    p.total_stage = acc;
-    acc = 0;
     for (uint32_t t = 0; t < p.n_slices; ++t) { h_shead[t] = acc; acc += h_K[t]; }
     p.total_chunks = acc;
-    p.cap = p.max_stage + 1 <= 1024 ? 1024 : (p.max_stage + 1 <= 2048 ? 2048 : 4096);
-
-    AZP_HIP_TRY(ensure(p.d_stage_idx, p.cap_stage, (size_t)std::max<uint64_t>(p.total_stage, 1)));
     AZP_HIP_TRY(ensure(p.d_cnl, p.cap_cnl, (size_t)std::max<uint64_t>(p.total_chunks * 64, 1)));
-    AZP_HIP_TRY(hipMemcpyAsync(p.d_tile_head, h_thead.data(), sizeof(uint64_t) * p.n_tiles, hipMemcpyHostToDevice, s));
     AZP_HIP_TRY(hipMemcpyAsync(p.d_slice_head, h_shead.data(), sizeof(uint64_t) * p.n_slices, hipMemcpyHostToDevice, s));
-    k.stage_idx = p.d_stage_idx;
-    k.cnl = p.d_cnl;
-    launch_plan(tpp, true, k, p.n_tiles, s);
-    AZP_HIP_TRY(hipGetLastError());
-    // the host vectors must outlive the async copies
-    AZP_HIP_TRY(hipStreamSynchronize(s));
+
+    // stage stride: last build's maximum + 25 % (first build: full budget if it fits
+    // in 256 MiB, else a first guess), rounded to 64; retried larger on overflow
+    uint32_t stride = p.stage_stride_hint;
+    if (stride == 0)
+        stride = ((uint64_t)p.n_tiles * (PLAN_MAX_STAGE + 1) * 4 <= (256ull << 20)) ? PLAN_MAX_STAGE + 1 : 1536;
+    for (;;)
+        {
+        stride = std::min<uint32_t>((stride + 63u) & ~63u, PLAN_MAX_STAGE + 1);
+        AZP_HIP_TRY(ensure(p.d_stage_idx, p.cap_stage, (size_t)p.n_tiles * stride));
+        AZP_HIP_TRY(hipMemsetAsync(p.d_flags, 0, 4 * sizeof(uint32_t), s));
+        k.stage_idx = p.d_stage_idx;
+        k.cnl = p.d_cnl;
+        k.stage_stride = stride;
+        AZP_HIP_TRY(launch_plan(tpp, 1, k, p.n_tiles, s));
+        AZP_HIP_TRY(hipMemcpyAsync(h_flags, p.d_flags, sizeof(h_flags), hipMemcpyDeviceToHost, s));
+        AZP_HIP_TRY(hipStreamSynchronize(s));
+        p.max_stage = h_flags[2];
+        if (!h_flags[1])
+            break;
+        if (p.max_stage > PLAN_MAX_STAGE || stride >= PLAN_MAX_STAGE + 1)
+            {
+            p.invalid_reason = 2;
+            return AZP_SUCCESS;
+            }
+        stride = p.max_stage + p.max_stage / 8 + 64; // the stride was the problem: grow and redo
+        }
+    p.stage_stride_hint = p.max_stage + p.max_stage / 4 + 64;
+    p.total_stage = (uint64_t)p.n_tiles * stride;
+    p.cap = p.max_stage + 1 <= 1024 ? 1024 : (p.max_stage + 1 <= 1536 ? 1536 : (p.max_stage + 1 <= 2048 ? 2048 : 2560));
     p.valid = true;
     return AZP_SUCCESS;
     }
@@ -362,7 +578,8 @@ extern "C" void azp_pair_plan_destroy(azp_pair_plan* plan)
 
 extern "C" int azp_pair_plan_build(azp_pair_plan* plan, const azp_pair_args* args, void* stream)
     {
-    if (!plan || !args || !args->d_pos || !args->d_n_neigh || !args->d_nlist || !args->d_head_list)
+    if (!plan || !args || !args->d_pos || !args->d_n_neigh || !args->d_nlist || !args->d_head_list || !args->d_rcutsq
+        || args->ntypes == 0)
         return AZP_ERROR_INVALID_ARGUMENT;
     return azp::plan_build(*reinterpret_cast<azp::PairPlan*>(plan), *args, static_cast<hipStream_t>(stream));
     }

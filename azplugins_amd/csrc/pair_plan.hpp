@@ -29,9 +29,12 @@
 
 namespace azp
 {
-constexpr uint32_t PLAN_HASH_CAP = 8192;     // LDS hash-set capacity per tile (build only)
-constexpr uint32_t PLAN_MAX_STAGE = 4095;    // + dummy slot 0 => <= 4096 LDS slots (u16 offset = slot*8 < 65536)
+constexpr uint32_t PLAN_HASH_CAP = 8192;     // largest LDS hash-set capacity per tile (build only)
+constexpr uint32_t PLAN_MAX_STAGE = 2559;    // + dummy slot 0 => <= 2560 LDS slots (fill pass: 76 KB + 28 B/slot of LDS)
 constexpr uint32_t PLAN_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t PLAN_BITMAP_WORDS = 80;    // 2560 slots / 32
+constexpr uint32_t PLAN_ROWBUF = 512;         // compiled entries per row the builder can hold (rows longer than
+                                              // this invalidate the plan)
 constexpr double PLAN_FAR = 1.0e30;          // coordinate of the dummy slot
 
 struct PairPlan
@@ -39,7 +42,7 @@ struct PairPlan
     // configuration chosen at build time
     uint32_t tpp = 0;          // lanes per particle (1, 2, 4)
     uint32_t tile = 0;         // particles per tile = 4 waves * 64 / tpp
-    uint32_t cap = 0;          // LDS slots the force kernel must provide (1024 / 2048 / 4096)
+    uint32_t cap = 0;          // LDS slots the force kernel must provide (1024 / 1536 / 2048 / 2560)
     // what it was built for
     uint32_t N = 0, n_max = 0;
     const uint32_t* nlist_ptr = nullptr;
@@ -61,6 +64,7 @@ struct PairPlan
     uint32_t* d_flags = nullptr;           // [1] stage overflow, [2] max staged set
     size_t cap_tiles = 0, cap_slices = 0, cap_stage = 0, cap_cnl = 0;
     uint64_t builds = 0;
+    uint32_t stage_stride_hint = 0; // stage_idx entries to reserve per tile next time (last max + 25 %)
     };
 
 } // namespace azp

@@ -18,6 +18,10 @@
 #include "pair_kernel.hpp"
 #include "pair_plan.hpp"
 
+#ifndef AZP_TILED_WAVES_PER_SIMD
+#define AZP_TILED_WAVES_PER_SIMD 4 // register budget: <= 128 VGPRs => 4 workgroups (of 4 waves) per CU
+#endif
+
 namespace azp
 {
 struct TiledKArgs
@@ -31,78 +35,113 @@ struct TiledKArgs
     const uint4* cnl;
     };
 
-// Half a chunk's worth of gathered neighbor data (4 neighbors of this lane).
+#ifndef AZP_TILE_BATCH
+#define AZP_TILE_BATCH 4 // pairs per register batch: 4 = half a chunk, 8 = a whole chunk
+#endif
+
+// A batch of gathered neighbor data (NB = 4: half a chunk, NB = 8: a whole chunk).
 struct TileBatch
     {
-    double x[4], y[4], z[4];
-    uint32_t off[4];
+    double x[AZP_TILE_BATCH], y[AZP_TILE_BATCH], z[AZP_TILE_BATCH];
+    uint32_t off[AZP_TILE_BATCH];
     };
 
-// phase 1: issue the 12 LDS gathers of half H (0 or 1) of a chunk
+// phase 1: issue the LDS gathers of a batch (half H of the chunk when NB = 4)
 template<int CAP, int H> __device__ __forceinline__ void tile_gather(TileBatch& b, const uint4& u, const char* bx)
     {
-    const uint32_t w0 = H ? u.z : u.x, w1 = H ? u.w : u.y;
-    b.off[0] = w0 & 0xffffu;
-    b.off[1] = w0 >> 16;
-    b.off[2] = w1 & 0xffffu;
-    b.off[3] = w1 >> 16;
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
+    constexpr int NB = AZP_TILE_BATCH;
+    if (NB == 4)
         {
+        const uint32_t w0 = H ? u.z : u.x, w1 = H ? u.w : u.y;
+        b.off[0] = w0 & 0xffffu;
+        b.off[1] = w0 >> 16;
+        b.off[2] = w1 & 0xffffu;
+        b.off[3] = w1 >> 16;
+        }
+    else
+        {
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < NB; ++e)
+            b.off[e] = (e & 1) ? (w[(e >> 1) & 3] >> 16) : (w[(e >> 1) & 3] & 0xffffu);
+        }
+#pragma unroll
+    for (int e = 0; e < NB; ++e)
+        {
+#if defined(AZP_ABLATE) && (AZP_ABLATE == 2)
+        b.x[e] = (double)b.off[e]; b.y[e] = 1.0; b.z[e] = 2.0; // ablation 2: no LDS gathers
+#else
         b.x[e] = *reinterpret_cast<const double*>(bx + b.off[e]);
         b.y[e] = *reinterpret_cast<const double*>(bx + b.off[e] + CAP * 8);
         b.z[e] = *reinterpret_cast<const double*>(bx + b.off[e] + CAP * 16);
+#endif
         }
     }
 
-// phase 2: arithmetic on a gathered half chunk
+// phase 2: arithmetic on a gathered half chunk. The separations of the 4 pairs
+// are formed first; if no lane of the wave has any of them inside the (largest)
+// cutoff, the evaluator work is skipped -- exact, and the common case at the far
+// end of the near-first ordered rows.
 template<class E, int CAP, bool VIRIAL, bool SINGLE, bool XPLOR, bool WRAP>
 __device__ __forceinline__ void tile_compute(const TileBatch& b, const TiledKArgs& a, const char* bt,
                                              const typename E::Coeff* __restrict__ s_coeff,
                                              const double* __restrict__ s_ronsq, const typename E::Coeff& c0, double ronsq0,
-                                             const double3& pi, int typei, double& fx, double& fy, double& fz, double& pe,
-                                             double (&v)[6])
+                                             double rcutsq_max, const double3& pi, int typei, double& fx, double& fy,
+                                             double& fz, double& pe, double (&v)[6])
     {
     typedef typename E::Coeff Coeff;
+    constexpr int NB = AZP_TILE_BATCH;
+    double dx[NB], dy[NB], dz[NB], rsq[NB];
+    bool any_in = false;
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int e = 0; e < NB; ++e)
         {
-        const uint32_t off = b.off[e];
-        double dx = pi.x - b.x[e], dy = pi.y - b.y[e], dz = pi.z - b.z[e];
+        dx[e] = pi.x - b.x[e]; dy[e] = pi.y - b.y[e]; dz[e] = pi.z - b.z[e];
         if (WRAP)
-            min_image(a.p.box, dx, dy, dz);
-        double rsq = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
+            min_image(a.p.box, dx[e], dy[e], dz[e]);
+        rsq[e] = __builtin_fma(dz[e], dz[e], __builtin_fma(dy[e], dy[e], dx[e] * dx[e]));
         if (WRAP)
-            rsq = (off == 0) ? 1.0e300 : rsq; // the minimum image would fold the padding slot back into the box
+            rsq[e] = (b.off[e] == 0) ? 1.0e300 : rsq[e]; // the minimum image would fold the padding slot back into the box
+        any_in = any_in || (rsq[e] < rcutsq_max);
+        }
+#if defined(AZP_ABLATE) && (AZP_ABLATE == 3)
+    fx += rsq[0] + rsq[1] + rsq[2] + rsq[3]; // ablation 3: gathers + separations only
+    return;
+#endif
+    if (!__any(any_in))
+        return;
+#pragma unroll
+    for (int e = 0; e < NB; ++e)
+        {
         double force_divr, pair_eng;
         if (SINGLE)
             {
-            const bool evaluated = E::eval(c0, rsq, force_divr, pair_eng);
+            const bool evaluated = E::eval(c0, rsq[e], force_divr, pair_eng);
             if (XPLOR && evaluated)
-                apply_xplor(rsq, ronsq0, c0.rcutsq, force_divr, pair_eng);
+                apply_xplor(rsq[e], ronsq0, c0.rcutsq, force_divr, pair_eng);
             }
         else
             {
-            const int typej = *reinterpret_cast<const int*>(bt + (off >> 1));
+            const int typej = *reinterpret_cast<const int*>(bt + (b.off[e] >> 1));
             const uint32_t tp = (uint32_t)typei * a.p.ntypes + (uint32_t)typej;
             const Coeff cc = s_coeff[tp];
-            const bool evaluated = E::eval(cc, rsq, force_divr, pair_eng);
+            const bool evaluated = E::eval(cc, rsq[e], force_divr, pair_eng);
             if (XPLOR && evaluated)
-                apply_xplor(rsq, s_ronsq[tp], cc.rcutsq, force_divr, pair_eng);
+                apply_xplor(rsq[e], s_ronsq[tp], cc.rcutsq, force_divr, pair_eng);
             }
-        fx = __builtin_fma(dx, force_divr, fx);
-        fy = __builtin_fma(dy, force_divr, fy);
-        fz = __builtin_fma(dz, force_divr, fz);
+        fx = __builtin_fma(dx[e], force_divr, fx);
+        fy = __builtin_fma(dy[e], force_divr, fy);
+        fz = __builtin_fma(dz[e], force_divr, fz);
         pe += pair_eng;
         if (VIRIAL)
             {
-            const double fxx = force_divr * dx, fyy = force_divr * dy;
-            v[0] = __builtin_fma(fxx, dx, v[0]);
-            v[1] = __builtin_fma(fxx, dy, v[1]);
-            v[2] = __builtin_fma(fxx, dz, v[2]);
-            v[3] = __builtin_fma(fyy, dy, v[3]);
-            v[4] = __builtin_fma(fyy, dz, v[4]);
-            v[5] = __builtin_fma(force_divr * dz, dz, v[5]);
+            const double fxx = force_divr * dx[e], fyy = force_divr * dy[e];
+            v[0] = __builtin_fma(fxx, dx[e], v[0]);
+            v[1] = __builtin_fma(fxx, dy[e], v[1]);
+            v[2] = __builtin_fma(fxx, dz[e], v[2]);
+            v[3] = __builtin_fma(fyy, dy[e], v[3]);
+            v[4] = __builtin_fma(fyy, dz[e], v[4]);
+            v[5] = __builtin_fma(force_divr * dz[e], dz[e], v[5]);
             }
         }
     }
@@ -117,10 +156,11 @@ template<class E, int TPP, int CAP, bool VIRIAL, bool SINGLE, bool XPLOR, bool W
 __device__ __forceinline__ void tiled_loop(const TiledKArgs& a, const char* bx, const char* bt,
                                            const typename E::Coeff* __restrict__ s_coeff,
                                            const double* __restrict__ s_ronsq, const typename E::Coeff& c0, double ronsq0,
-                                           const uint4* __restrict__ chunks, uint32_t K, double3 pi, int typei,
-                                           double& fx, double& fy, double& fz, double& pe, double (&v)[6])
+                                           double rcutsq_max, const uint4* __restrict__ chunks, uint32_t K, double3 pi,
+                                           int typei, double& fx, double& fy, double& fz, double& pe, double (&v)[6])
     {
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
+#if AZP_TILE_BATCH == 4
     uint4 u = (K > 0) ? chunks[0] : zero4;
     TileBatch A, B;
     tile_gather<CAP, 0>(A, u, bx);
@@ -129,18 +169,40 @@ __device__ __forceinline__ void tiled_loop(const TiledKArgs& a, const char* bx, 
         const uint4 un = (kk + 1 < K) ? chunks[(uint64_t)(kk + 1) * 64] : zero4; // next chunk's indices
         tile_gather<CAP, 1>(B, u, bx);
         __builtin_amdgcn_sched_barrier(0);
-        tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(A, a, bt, s_coeff, s_ronsq, c0, ronsq0, pi, typei, fx, fy, fz, pe, v);
+        tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(A, a, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, pi, typei, fx, fy, fz, pe, v);
         __builtin_amdgcn_sched_barrier(0);
         tile_gather<CAP, 0>(A, un, bx); // padding slot when kk + 1 == K: gathered, never used
         __builtin_amdgcn_sched_barrier(0);
-        tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(B, a, bt, s_coeff, s_ronsq, c0, ronsq0, pi, typei, fx, fy, fz, pe, v);
+        tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(B, a, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, pi, typei, fx, fy, fz, pe, v);
         __builtin_amdgcn_sched_barrier(0);
         u = un;
         }
+#else
+    // whole-chunk batches: chunk k+1's 24 gathers fly while chunk k is evaluated
+    uint4 u0 = (K > 0) ? chunks[0] : zero4;
+    uint4 u1 = (K > 1) ? chunks[64] : zero4;
+    TileBatch A, B;
+    tile_gather<CAP, 0>(A, u0, bx);
+    for (uint32_t kk = 0; kk < K; kk += 2)
+        {
+        const uint4 u2 = (kk + 2 < K) ? chunks[(uint64_t)(kk + 2) * 64] : zero4;
+        const uint4 u3 = (kk + 3 < K) ? chunks[(uint64_t)(kk + 3) * 64] : zero4;
+        tile_gather<CAP, 0>(B, u1, bx);
+        __builtin_amdgcn_sched_barrier(0);
+        tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(A, a, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, pi, typei, fx, fy, fz, pe, v);
+        __builtin_amdgcn_sched_barrier(0);
+        tile_gather<CAP, 0>(A, u2, bx);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk + 1 < K)
+            tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(B, a, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, pi, typei, fx, fy, fz, pe, v);
+        __builtin_amdgcn_sched_barrier(0);
+        u1 = u3;
+        }
+#endif
     }
 
 template<class E, int TPP, int CAP, bool VIRIAL, bool SINGLE, bool XPLOR>
-__global__ void __launch_bounds__(256) pair_forces_tiled_kernel(const TiledKArgs a, const typename E::Params* __restrict__ params)
+__global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_tiled_kernel(const TiledKArgs a, const typename E::Params* __restrict__ params)
     {
     typedef typename E::Coeff Coeff;
     constexpr int TB = 256 / TPP;
@@ -161,11 +223,13 @@ __global__ void __launch_bounds__(256) pair_forces_tiled_kernel(const TiledKArgs
 
     Coeff c0;
     double ronsq0 = 0.0;
+    double rcutsq_max = 0.0; // largest cutoff^2 over the type pairs: bound for the skip test
     if (SINGLE)
         {
         c0 = prepare_coeff<E>(a.p, params, 0);
         if (XPLOR)
             ronsq0 = a.p.ronsq[0];
+        rcutsq_max = a.p.rcutsq[0];
         }
     else
         {
@@ -175,6 +239,8 @@ __global__ void __launch_bounds__(256) pair_forces_tiled_kernel(const TiledKArgs
             s_coeff[t] = prepare_coeff<E>(a.p, params, t);
             s_ronsq[t] = XPLOR ? a.p.ronsq[t] : 0.0;
             }
+        for (uint32_t t = 0; t < ntp; ++t)
+            rcutsq_max = fmax(rcutsq_max, a.p.rcutsq[t]);
         }
 
     // ---- stage: positions shifted to the periodic image nearest the tile's
@@ -187,7 +253,11 @@ __global__ void __launch_bounds__(256) pair_forces_tiled_kernel(const TiledKArgs
         s_x[0] = PLAN_FAR; s_y[0] = PLAN_FAR; s_z[0] = PLAN_FAR;
         if (!SINGLE) s_t[0] = 0;
         }
+#if defined(AZP_ABLATE) && (AZP_ABLATE == 1)
+    for (uint32_t s = tid; s < 0 * n_stage; s += 256) // ablation 1: no staging loads
+#else
     for (uint32_t s = tid; s < n_stage; s += 256)
+#endif
         {
         const uint32_t j = stage[s];
         double x, y, z;
@@ -249,11 +319,11 @@ __global__ void __launch_bounds__(256) pair_forces_tiled_kernel(const TiledKArgs
     const char* bx = reinterpret_cast<const char*>(s_x);
     const char* bt = reinterpret_cast<const char*>(s_t);
     if (wide)
-        tiled_loop<E, TPP, CAP, VIRIAL, SINGLE, XPLOR, true>(a, bx, bt, s_coeff, s_ronsq, c0, ronsq0, chunks, K, pi, typei,
-                                                            fx, fy, fz, pe, v);
+        tiled_loop<E, TPP, CAP, VIRIAL, SINGLE, XPLOR, true>(a, bx, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, chunks, K, pi,
+                                                            typei, fx, fy, fz, pe, v);
     else
-        tiled_loop<E, TPP, CAP, VIRIAL, SINGLE, XPLOR, false>(a, bx, bt, s_coeff, s_ronsq, c0, ronsq0, chunks, K, pi, typei,
-                                                             fx, fy, fz, pe, v);
+        tiled_loop<E, TPP, CAP, VIRIAL, SINGLE, XPLOR, false>(a, bx, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, chunks, K, pi,
+                                                             typei, fx, fy, fz, pe, v);
 
     fx = group_sum<TPP>(fx);
     fy = group_sum<TPP>(fy);
@@ -325,8 +395,9 @@ int launch_tiled_cap(const PairPlan& plan, const azp_pair_args& args, const type
     switch (plan.cap)
         {
     case 1024: return launch_tiled_instance<E, TPP, 1024, VIRIAL, SINGLE>(plan, args, d_params, s);
+    case 1536: return launch_tiled_instance<E, TPP, 1536, VIRIAL, SINGLE>(plan, args, d_params, s);
     case 2048: return launch_tiled_instance<E, TPP, 2048, VIRIAL, SINGLE>(plan, args, d_params, s);
-    case 4096: return launch_tiled_instance<E, TPP, 4096, VIRIAL, SINGLE>(plan, args, d_params, s);
+    case 2560: return launch_tiled_instance<E, TPP, 2560, VIRIAL, SINGLE>(plan, args, d_params, s);
     default: return AZP_ERROR_INVALID_ARGUMENT;
         }
     }

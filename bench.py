@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="none", choices=["none", "shift", "xplor"])
     ap.add_argument("--no-plan", action="store_true", help="generic kernel only (no LDS-staged tile plan)")
+    ap.add_argument("--sort-rows", action="store_true", help="experiment: sort every neighbor row by index before planning")
     args = ap.parse_args()
 
     import torch
@@ -125,6 +126,13 @@ def main():
     pot.use_plan = not args.no_plan
     sim.operations.integrator = azp.Integrator(dt=0.005, forces=[pot])
     sim.run(0)  # attaches, builds the neighbor list (and the tile plan) on the GPU, first force evaluation
+    if args.sort_rows:
+        row = torch.repeat_interleave(torch.arange(N, device=dev, dtype=torch.int64), nl.n_neigh.to(torch.int64))
+        key = (row << 32) | nl.nlist[: nl.size].to(torch.int64)
+        nl.nlist[: nl.size] = (torch.sort(key).values & 0xFFFFFFFF).to(torch.int32)
+        nl.num_builds += 1  # forces a plan rebuild
+        del row, key
+        pot.compute(0)
     mean_neigh = nl.size / N
 
     for _ in range(args.warmup):

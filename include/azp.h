@@ -154,7 +154,7 @@ int azp_pair_forces_dpd_conservative(const azp_pair_args* args, const azp_dpd_pa
  * NeighborList::getNumUpdates() changed) -- it synchronises the stream and may
  * (re)allocate device workspace owned by the plan -- then call the *_planned
  * entry points every step. If the list cannot be tiled (a tile's neighbor set
- * exceeds 4095 particles, e.g. unsorted particle order) the plan is marked
+ * exceeds 2559 particles or a row exceeds ~1000 entries, e.g. unsorted particle order) the plan is marked
  * invalid and the planned entry points run the generic kernel instead. Tiles
  * that are wide compared with the box, triclinic boxes, or calls without the
  * r_list_max hint re-apply the minimum image per pair (slower, still exact).
@@ -164,7 +164,7 @@ typedef struct azp_pair_plan azp_pair_plan; /* opaque */
 typedef struct azp_pair_plan_info
     {
     int32_t valid;
-    int32_t invalid_reason;      /* 0 none, 2: a tile lists more than 4095 distinct neighbors */
+    int32_t invalid_reason;      /* 0 none, 2: a tile lists more than 2559 distinct neighbors (or a row is too long) */
     uint32_t threads_per_particle;
     uint32_t tile_size;          /* particles per tile (workgroup) */
     uint32_t lds_slots;          /* staged-position capacity the kernel is instantiated for */
