@@ -44,6 +44,22 @@ def make_workload(name):
     raise SystemExit("unknown workload %r" % name)
 
 
+def measured_traffic(kernel, workload):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/r*_traffic.json), or None. bench.py cannot collect PMC counters
+    itself; the JSON names the passes it came from."""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f)).get(kernel)
+        except (OSError, ValueError):
+            continue
+        if d and d.get("workload", "").lower() == workload.lower():
+            return (d["FETCH_SIZE_KiB"] * d.get("fetch_correction", 1.0) + d["WRITE_SIZE_KiB"]) * 1024.0, os.path.basename(f)
+    return None, None
+
+
 def cpu_baseline(workload, reps=5):
     """HOOMD-equivalent CPU loop restated (oracle): half neighbor list, third-law
     scatter, FP64, ONE core (HOOMD's per-rank CPU execution model), timed on
@@ -67,8 +83,12 @@ def cpu_baseline(workload, reps=5):
     out = dict(value=N / t, unit="particle-steps/s", cores=1, kind="port",
                sample="%s: same lattice/density/potential, N=%d (1/8 of the workload), half list, median of %d "
                       "reps; oracle = HOOMD-equivalent loop restated, not the HOOMD binary" % (cfg["name"], N, reps))
-    # best-effort all-core figure (OpenMP over particles, full list)
-    ncores = os.cpu_count() or 1
+    # best-effort all-core figure (OpenMP over particles, full list), on this process's CPU share
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    ncores = min(ncores, 16)
     nl_full = oracle.build_nlist(pos, box, cfg["r_cut"] + cfg["r_buff"], half=False)
     ts = []
     for _ in range(reps):
@@ -154,6 +174,9 @@ def main():
     b_alg = alg_bytes_per_particle(mean_neigh)
     achieved = b_alg * N / (kernel_ms * 1e-3) / 1e9
     launch = azp._lib.last_launch()
+    kernel_name = ("azp::pair_forces_tiled_kernel<EvalPLJ>" if (pot.plan_info or {}).get("valid")
+                   else "azp::pair_forces_kernel<EvalPLJ>")
+    traffic, traffic_src = measured_traffic(kernel_name, cfg["name"])
     out = {
         "metric": "particle-steps/sec, PerturbedLennardJones pair force",
         "value": value,
@@ -184,8 +207,9 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
-            "traffic": None,
-            "kernel": "azp::pair_forces_tiled_kernel<EvalPLJ>" if (pot.plan_info or {}).get("valid") else "azp::pair_forces_kernel<EvalPLJ>",
+            "traffic": traffic,
+            "traffic_source": traffic_src,
+            "kernel": kernel_name,
             "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_particle": b_alg,
         },
