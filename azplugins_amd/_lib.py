@@ -44,6 +44,8 @@ class PairArgs(C.Structure):
         ("block_size", C.c_uint32),
         ("threads_per_particle", C.c_uint32),
         ("_pad", C.c_uint32),
+        ("range_first", C.c_uint32),
+        ("range_count", C.c_uint32),
         ("r_list_max", C.c_double),
     ]
 

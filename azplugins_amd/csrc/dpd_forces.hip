@@ -126,9 +126,9 @@ __global__ void __launch_bounds__(256) dpd_forces_kernel(const DPDKArgs a, const
         }
 
     const uint32_t block = xcd_remap(blockIdx.x, a.p.nblocks_padded);
-    const uint32_t idx = block * (blockDim.x / TPP) + threadIdx.x / TPP;
+    const uint32_t idx = a.p.first + block * (blockDim.x / TPP) + threadIdx.x / TPP;
     const uint32_t sub = threadIdx.x % TPP;
-    const bool active = idx < a.p.N;
+    const bool active = idx < a.p.end;
 
     uint32_t n = 0, tagi = 0;
     uint64_t head = 0;
@@ -185,7 +185,7 @@ static int launch_dpd_instance(const azp_dpd_args& args, DPDKArgs k, const azp_d
                                hipStream_t stream)
     {
     const uint32_t groups = bs / TPP;
-    uint32_t nblocks = (args.pair.N + groups - 1) / groups;
+    uint32_t nblocks = (k.p.end - k.p.first + groups - 1) / groups;
     nblocks = (nblocks + 7u) & ~7u;
     k.p.nblocks_padded = nblocks;
     size_t lds = SINGLE ? 0 : sizeof(DPDCoeff) * (size_t)args.pair.ntypes * args.pair.ntypes;

@@ -39,6 +39,8 @@ struct PairKArgs
     uint32_t ntypes;
     uint32_t shift_mode;
     uint32_t nblocks_padded; // grid size, multiple of 8
+    uint32_t first;          // particles [first, end) are computed by this launch
+    uint32_t end;
     };
 
 template<class E> __device__ __forceinline__ typename E::Coeff
@@ -146,9 +148,9 @@ __global__ void __launch_bounds__(256) pair_forces_kernel(const PairKArgs a, con
 
     const uint32_t block = xcd_remap(blockIdx.x, a.nblocks_padded);
     const uint32_t groups_per_block = blockDim.x / TPP;
-    const uint32_t idx = block * groups_per_block + threadIdx.x / TPP;
+    const uint32_t idx = a.first + block * groups_per_block + threadIdx.x / TPP;
     const uint32_t sub = threadIdx.x % TPP;
-    const bool active = idx < a.N;
+    const bool active = idx < a.end;
 
     uint32_t n = 0;
     uint64_t head = 0;
@@ -225,7 +227,7 @@ int launch_pair_instance2(const azp_pair_args& args, const PairKArgs& k, const t
     {
     PairKArgs ka = k;
     const uint32_t groups_per_block = block_size / TPP;
-    uint32_t nblocks = (args.N + groups_per_block - 1) / groups_per_block;
+    uint32_t nblocks = (ka.end - ka.first + groups_per_block - 1) / groups_per_block;
     nblocks = (nblocks + 7u) & ~7u;
     ka.nblocks_padded = nblocks;
     size_t lds = 0;
@@ -283,6 +285,7 @@ inline int validate_pair_args(const azp_pair_args* args, const void* d_params)
     if (args->compute_virial && (!args->d_virial || args->virial_pitch < args->N)) return AZP_ERROR_INVALID_ARGUMENT;
     if (args->n_max < args->N) return AZP_ERROR_INVALID_ARGUMENT;
     if (args->block_size && (args->block_size % 64 || args->block_size > 256)) return AZP_ERROR_INVALID_ARGUMENT;
+    if (args->range_count && (uint64_t)args->range_first + args->range_count > args->N) return AZP_ERROR_INVALID_ARGUMENT;
     return 0;
     }
 
@@ -304,6 +307,8 @@ inline PairKArgs make_pair_kargs(const azp_pair_args& args)
     k.ntypes = args.ntypes;
     k.shift_mode = args.shift_mode;
     k.nblocks_padded = 0;
+    k.first = args.range_count ? args.range_first : 0u;
+    k.end = args.range_count ? args.range_first + args.range_count : args.N;
     return k;
     }
 

@@ -216,9 +216,10 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
     double* s_ronsq = reinterpret_cast<double*>(s_coeff + (SINGLE ? 0 : a.p.ntypes * a.p.ntypes));
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t tile = xcd_remap(blockIdx.x, a.p.nblocks_padded);
+    // a.p.first / a.p.end are tile-aligned outwards by the launcher
+    const uint32_t tile = a.p.first / TB + xcd_remap(blockIdx.x, a.p.nblocks_padded);
     const uint32_t first = tile * TB;
-    if (first >= a.p.N)
+    if (first >= a.p.end)
         return;
 
     Coeff c0;
@@ -285,7 +286,7 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
     const uint32_t wave = tid >> 6, lane = tid & 63;
     const uint32_t pl = lane / TPP;
     const uint32_t idx = first + wave * PW + pl;
-    const bool active = idx < a.p.N;
+    const bool active = idx < a.p.end;
     double3 pi = make_double3(0.0, 0.0, 0.0);
     int typei = 0;
     // Fast path condition, per tile: every member is closer to c than L/2 minus
@@ -359,7 +360,13 @@ int launch_tiled_instance2(const PairPlan& plan, const azp_pair_args& args, cons
     k.slice_K = plan.d_slice_K;
     k.slice_head = plan.d_slice_head;
     k.cnl = plan.d_cnl;
-    const uint32_t nblocks = (plan.n_tiles + 7u) & ~7u;
+    // sub-range launches are rounded outwards to whole tiles (a tile computed by
+    // two launches of one step gets the later launch's values: stream order)
+    const uint32_t tb = plan.tile;
+    const uint32_t t0 = k.p.first / tb, t1 = (k.p.end + tb - 1) / tb;
+    k.p.first = t0 * tb;
+    k.p.end = (t1 * tb < args.N) ? t1 * tb : args.N;
+    const uint32_t nblocks = (t1 - t0 + 7u) & ~7u;
     k.p.nblocks_padded = nblocks;
     size_t lds = (size_t)CAP * (SINGLE ? 24 : 28);
     if (!SINGLE)

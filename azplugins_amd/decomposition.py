@@ -74,6 +74,18 @@ class Decomposition:
         lo = -0.5 * self.L + c * self.width
         return lo, lo + self.width
 
+    def depth(self, xyz, rank):
+        """Distance of each position to the nearest decomposed face of rank's
+        sub-box (inf when no axis is decomposed): particles deeper than the list
+        radius cannot have a ghost neighbor."""
+        lo, hi = self.bounds(rank)
+        d = np.full(xyz.shape[0], np.inf)
+        for k in range(3):
+            if self.grid[k] == 1:
+                continue
+            d = np.minimum(d, np.minimum(xyz[:, k] - lo[k], hi[k] - xyz[:, k]))
+        return d
+
     def in_ghost_shell(self, xyz, rank):
         """True for particles within r_ghost of rank's sub-box (periodic), i.e.
         local particles and ghosts of that rank."""
@@ -103,7 +115,13 @@ class RankDomain:
         self.rank = rank
         owner = decomp.owner(xyz_global)
         self.owner = owner
-        self.local_gid = np.flatnonzero(owner == rank)
+        local = np.flatnonzero(owner == rank)
+        # interior particles first, then the shell that can see ghosts; the spatial
+        # (global) order is kept inside each group. Forces of the interior group do
+        # not depend on the halo, so they overlap with the exchange.
+        shell_local = decomp.depth(xyz_global[local], rank) < decomp.r_ghost
+        self.local_gid = np.concatenate([local[~shell_local], local[shell_local]])
+        self.n_interior = int((~shell_local).sum())
         shell = decomp.in_ghost_shell(xyz_global, rank)
         ghost_mask = shell & (owner != rank)
         ghost_gid = np.flatnonzero(ghost_mask)
@@ -121,6 +139,8 @@ class RankDomain:
                 continue
             need = decomp.in_ghost_shell(xyz_global[self.local_gid], peer)
             idx = np.flatnonzero(need)
+            # ascending GLOBAL id, the order in which the peer lists its ghosts
+            idx = idx[np.argsort(self.local_gid[idx], kind="stable")]
             self.send_counts[peer] = idx.size
             send_idx.append((peer, idx))
         self.send_idx = np.concatenate([i for _, i in sorted(send_idx)]) if send_idx else np.zeros(0, dtype=np.int64)
@@ -149,32 +169,45 @@ class HaloExchange:
         self._bufs = {}
         self.bytes_sent_per_step = 0
 
-    def _buf(self, like, width):
-        key = (like.dtype, width)
+    def _buf(self, like, width, slot=0):
+        key = (like.dtype, width, slot)
         if key not in self._bufs:
             import torch
 
             self._bufs[key] = torch.empty((self.send_idx.numel(), width), dtype=like.dtype, device=like.device)
         return self._bufs[key]
 
-    def exchange(self, *arrays):
-        """Each array is (N_local + n_ghost, w); rows [N_local:] are overwritten
-        with the owners' current rows."""
+    def pack(self, *arrays):
+        """Gather the rows the peers need into the send buffers (current stream)."""
         import torch
+
+        N = self.domain.N_local
+        out = []
+        for slot, a in enumerate(arrays):
+            a2 = a if a.dim() == 2 else a.unsqueeze(1)
+            buf = self._buf(a2, a2.shape[1], slot)
+            torch.index_select(a2[:N], 0, self.send_idx, out=buf)
+            out.append((a2, buf))
+        return out
+
+    def transfer(self, packed):
+        """all_to_all_single of the packed buffers straight into the ghost rows."""
         import torch.distributed as dist
 
         N = self.domain.N_local
         sent = 0
-        for a in arrays:
-            a2 = a if a.dim() == 2 else a.unsqueeze(1)
-            buf = self._buf(a2, a2.shape[1])
-            torch.index_select(a2[:N], 0, self.send_idx, out=buf)
+        for a2, buf in packed:
             ghost = a2[N:]
             if dist.is_initialized() and dist.get_world_size(self.group) > 1:
                 dist.all_to_all_single(ghost, buf, output_split_sizes=self.recv_splits,
                                        input_split_sizes=self.send_splits, group=self.group)
             sent += buf.numel() * buf.element_size()
         self.bytes_sent_per_step = sent
+
+    def exchange(self, *arrays):
+        """Each array is (N_local + n_ghost, w); rows [N_local:] are overwritten
+        with the owners' current rows."""
+        self.transfer(self.pack(*arrays))
 
 
 def build_rank_state(cfg, decomp, rank, device):
@@ -192,7 +225,15 @@ def build_rank_state(cfg, decomp, rank, device):
 
 
 def bench_main(args, rank, world, local_rank):
-    """bench.py for N > 1 GPUs: strong scaling of the north-star workload."""
+    """bench.py for N > 1 GPUs.
+
+    Default: WEAK scaling -- every GPU holds the north-star load (2^20 particles,
+    FCC 64^3 cells per GPU, so the global box is the rank grid times that) and the
+    job-wide rate is N_global / step time. ``--scaling strong`` keeps the global
+    problem at N = 2^20 instead.
+
+    One step = pack ghost rows -> all_to_all_single (RCCL) on a side stream ->
+    interior forces (overlapping the exchange) -> boundary forces."""
     import json
     import os
     import time
@@ -201,14 +242,21 @@ def bench_main(args, rank, world, local_rank):
     import torch.distributed as dist
 
     import azplugins_amd as azp
+    from azplugins_amd import synthetic as syn
     from bench import HBM_COPY_GBS, HBM_PEAK_GBS, alg_bytes_per_particle, make_workload
 
     dev = "cuda:%d" % local_rank
     dist.init_process_group(backend="nccl", device_id=torch.device(dev))
-    cfg = make_workload(args.workload)
+    weak = getattr(args, "scaling", "weak") == "weak" and args.workload == "ns"
+    if weak:
+        grid = choose_grid(world, np.ones(3))
+        cfg = syn.config_north_star(tuple(64 * g for g in grid))
+    else:
+        grid = None
+        cfg = make_workload(args.workload)
     N_global = cfg["xyz"].shape[0]
     r_ghost = cfg["r_cut"] + cfg["r_buff"]
-    decomp = Decomposition(cfg["L"], world, r_ghost)
+    decomp = Decomposition(cfg["L"], world, r_ghost, grid=grid)
     dom, state = build_rank_state(cfg, decomp, rank, dev)
     halo = HaloExchange(dom, dev)
 
@@ -225,33 +273,55 @@ def bench_main(args, rank, world, local_rank):
     sim.run(0)
     mean_neigh = nl.size / max(dom.N_local, 1)
 
+    main = torch.cuda.current_stream()
+    comm = torch.cuda.Stream()
+    n_int = dom.n_interior
+    n_bnd = dom.N_local - n_int
+    overlap = world > 1 and n_int > 0 and n_bnd > 0
+    if os.environ.get("AZP_BENCH_FORCE_OVERLAP") == "1" and not overlap:
+        # single-GPU rehearsal of the two-launch / two-stream step
+        n_int = dom.N_local // 2 + 77
+        n_bnd = dom.N_local - n_int
+        overlap = True
+
     def step():
-        halo.exchange(state.pos)   # ghost positions over RCCL/xGMI
-        pot.compute(0)             # forces for the local particles
+        packed = halo.pack(state.pos)           # gather the rows the peers need
+        if overlap:
+            comm.wait_stream(main)
+            with torch.cuda.stream(comm):
+                halo.transfer(packed)           # ghost positions over RCCL/xGMI
+            pot.compute(0, particle_range=(0, n_int))       # needs no ghost
+            main.wait_stream(comm)
+            pot.compute(0, particle_range=(n_int, n_bnd))   # shell particles
+        else:
+            halo.transfer(packed)
+            pot.compute(0)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    kernel_ms = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        halo.exchange(state.pos)
-        ev0.record()
-        pot.compute(0)
-        ev1.record()
+        step()
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1)  # last launch on this rank
+    # kernel time of one full force evaluation on this rank, outside the timed loop
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(10):
+        pot.compute(0)
+    ev1.record()
+    torch.cuda.synchronize()
+    kernel_ms = ev0.elapsed_time(ev1) / 10
     t = torch.tensor([wall], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
-    counts = torch.tensor([dom.N_local, dom.n_ghost], dtype=torch.int64, device=dev)
+    counts = torch.tensor([dom.N_local, dom.n_ghost, n_int], dtype=torch.int64, device=dev)
     gathered = [torch.zeros_like(counts) for _ in range(world)]
     dist.all_gather(gathered, counts)
 
@@ -267,18 +337,21 @@ def bench_main(args, rank, world, local_rank):
             "warmup": args.warmup,
             "ms_per_step": wall_max * 1e3 / args.steps,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak" if weak else "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "%s: PerturbedLennardJones N=%d (global) rho*=0.8 r_cut=%.1f buffer=%.1f mode=%s, spatial "
-                            "decomposition %dx%dx%d, ghost positions exchanged every step (all_to_all_single over RCCL)"
-                            % ((cfg["name"], N_global, cfg["r_cut"], cfg["r_buff"], args.mode) + decomp.grid),
+                "workload": "%s: PerturbedLennardJones N=%d global (%s: %d per GPU) rho*=0.8 r_cut=%.1f buffer=%.1f mode=%s, "
+                            "spatial decomposition %dx%dx%d, ghost positions exchanged every step "
+                            "(one all_to_all_single over RCCL into the ghost rows%s)"
+                            % ((cfg["name"], N_global, "weak scaling" if weak else "strong scaling", N_global // world,
+                                cfg["r_cut"], cfg["r_buff"], args.mode) + decomp.grid
+                               + (", overlapped with the interior forces" if overlap else "",)),
                 "N": N_global,
                 "mean_neighbors": mean_neigh,
                 "parallelism": "dd%d" % world,
-                "per_rank": [dict(N_local=int(g[0]), n_ghost=int(g[1])) for g in gathered],
+                "per_rank": [dict(N_local=int(g[0]), n_ghost=int(g[1]), n_interior=int(g[2])) for g in gathered],
                 "halo_bytes_sent_per_step_rank0": halo.bytes_sent_per_step,
                 "launch": azp._lib.last_launch(),
                 "tile_plan": pot.plan_info,
@@ -286,7 +359,7 @@ def bench_main(args, rank, world, local_rank):
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
-                "traffic": None, "kernel": "azp::pair_forces_kernel<EvalPLJ> (rank 0, last launch)",
+                "traffic": None, "kernel": "pair force kernel, rank 0, all local particles",
                 "kernel_ms": kernel_ms, "algorithmic_bytes_per_particle": b_alg,
             },
         }

@@ -137,9 +137,15 @@ class Pair(Force):
         a.block_size = self.block_size
         a.threads_per_particle = self.threads_per_particle
         a.r_list_max = nl.r_list_max
+        rng = getattr(self, "_range", None)
+        if rng is not None:
+            a.range_first, a.range_count = int(rng[0]), int(rng[1])
         return a
 
-    def compute(self, timestep=None):
+    def compute(self, timestep=None, particle_range=None):
+        """Evaluate the forces. ``particle_range=(first, count)`` restricts the
+        launch to a sub-range of the local particles (domain-decomposed runs compute
+        the interior while the halo exchange is in flight)."""
         import torch
 
         self._require()
@@ -148,7 +154,9 @@ class Pair(Force):
         if self._tables is None:
             self._build_tables()
         stream = torch.cuda.current_stream(st.device).cuda_stream
+        self._range = particle_range
         self._launch(stream, timestep)
+        self._range = None
         self._computed_generation = st.position_generation
 
     def _launch(self, stream, timestep):
@@ -159,7 +167,10 @@ class Pair(Force):
             key = (id(self.nlist), self.nlist.num_builds, self.threads_per_particle)
             if self._plan_builds != key:
                 # recompile the plan only when the neighbor list was rebuilt
+                first, count = a.range_first, a.range_count
+                a.range_first = a.range_count = 0
                 self._plan.build(a, stream)
+                a.range_first, a.range_count = first, count
                 self._plan_builds = key
             fn = getattr(_lib.lib(), self._planned_entry)
             _lib.check(fn(self._plan.handle, C.byref(a), self._tables["params"].data_ptr(), stream), self._planned_entry)

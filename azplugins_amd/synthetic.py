@@ -104,12 +104,14 @@ def simple_cubic(nx, ny, nz, a, jitter, seed):
 
 
 def fcc(ncell, a, jitter, seed):
-    """Jittered FCC lattice (4 sites per cubic cell). Returns (xyz, L)."""
-    ix, iy, iz = blocked_order(ncell, ncell, ncell)
+    """Jittered FCC lattice (4 sites per cubic cell); ``ncell`` is an int or a
+    (nx, ny, nz) tuple. Returns (xyz, L)."""
+    nx, ny, nz = (ncell, ncell, ncell) if np.isscalar(ncell) else ncell
+    ix, iy, iz = blocked_order(nx, ny, nz)
     basis = np.array([[0.0, 0.0, 0.0], [0.5, 0.5, 0.0], [0.5, 0.0, 0.5], [0.0, 0.5, 0.5]])
     cells = np.stack([ix, iy, iz], axis=1).astype(np.float64)
     xyz = ((cells[:, None, :] + basis[None, :, :] + 0.25) * a).reshape(-1, 3)
-    L = np.array([ncell * a] * 3)
+    L = np.array([nx * a, ny * a, nz * a])
     xyz = xyz - 0.5 * L + _jitter(seed, xyz.shape[0], jitter)
     return wrap(xyz, L), L
 
@@ -158,7 +160,8 @@ def config_north_star(ncell=64, seed=3):
     """PerturbedLJ north star: FCC ncell^3 x 4 at rho*=0.8 (N=1,048,576 for ncell=64)."""
     a = (4.0 / 0.8) ** (1.0 / 3.0)
     xyz, L = fcc(ncell, a, 0.05 * a, seed)
-    return dict(name="NS" if ncell == 64 else "NS-%d" % ncell, xyz=xyz, L=L, potential="PerturbedLennardJones",
+    name = "NS" if ncell == 64 else ("NS-%d" % ncell if np.isscalar(ncell) else "NS-%dx%dx%d" % tuple(ncell))
+    return dict(name=name, xyz=xyz, L=L, potential="PerturbedLennardJones",
                 params=dict(epsilon=1.0, sigma=1.0, attraction_scale_factor=0.5), r_cut=3.0, r_buff=0.4)
 
 

@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="none", choices=["none", "shift", "xplor"])
     ap.add_argument("--no-plan", action="store_true", help="generic kernel only (no LDS-staged tile plan)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1 GPUs: weak = 2^20 particles per GPU (default), strong = 2^20 in total")
     ap.add_argument("--sort-rows", action="store_true", help="experiment: sort every neighbor row by index before planning")
     args = ap.parse_args()
 
@@ -186,7 +188,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",

@@ -133,6 +133,10 @@ typedef struct azp_pair_args
     uint32_t block_size;         /* 0 = library default                             */
     uint32_t threads_per_particle; /* 0 = library heuristic; else 1,2,4,8,16,32     */
     uint32_t _pad;
+    uint32_t range_first;        /* compute only particles [range_first, range_first + */
+    uint32_t range_count;        /* range_count); range_count = 0 means all N. Lets a   */
+                                 /* caller overlap the ghost exchange with the interior */
+                                 /* particles (planned kernels round outwards to tiles) */
     double r_list_max;           /* optional: upper bound on the separation of any
                                     listed pair (r_cut_max + 2 r_buff); lets interior
                                     particles skip the minimum-image step. 0 = unknown. */

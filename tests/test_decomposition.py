@@ -88,11 +88,26 @@ def _worker(rank, world, port, out_dir):
     halo.exchange(pos, vel)
     assert np.array_equal(pos[dom.N_local:, :3].numpy(), moved(dom.ghost_gid))
     assert np.array_equal(vel[dom.N_local:, 0].numpy(), dom.ghost_gid.astype(np.float64))
+    # the split pack / transfer form used to overlap the exchange with interior forces
+    pos2 = pos.clone()
+    pos2[dom.N_local:] = 0.0
+    halo.transfer(halo.pack(pos2))
+    assert torch.equal(pos2, pos)
 
     # per-rank force compute (oracle as the kernel stand-in), global box min image
     box = oracle.make_box(cfg["L"])
     p = oracle.pack_pair_params("PerturbedLennardJones", cfg["params"])
     nl = oracle.build_nlist(pos.numpy(), box, r_cut + r_buff, N=dom.N_local)
+    # interior particles come first and list no ghost: their forces need no halo.
+    # (the domain was classified on the unmoved snapshot; particles moved by <= 0.087
+    # since, so test the ones that are still deeper than the list radius)
+    n_neigh, head, nlist = nl
+    assert np.all(dec.depth(cfg["xyz"][dom.local_gid[: dom.n_interior]], rank) >= dec.r_ghost)
+    assert np.all(dec.depth(cfg["xyz"][dom.local_gid[dom.n_interior:]], rank) < dec.r_ghost)
+    deep = np.flatnonzero(dec.depth(pos[: dom.N_local, :3].numpy(), rank) >= dec.r_ghost)
+    for i in deep:
+        assert (nlist[int(head[i]): int(head[i]) + int(n_neigh[i])] < dom.N_local).all()
+    assert (nlist >= dom.N_local).any()
     f = oracle.pair_forces("PerturbedLennardJones", pos.numpy(), box, nl, p, r_cut, mode="shift", N=dom.N_local)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), gid=dom.local_gid, force=f)
     dist.barrier()

@@ -460,3 +460,50 @@ def test_planned_plj_c2_full_size(oracle):
     f_again = H.gpu_pair_forces("PerturbedLennardJones", pos, (cfg["L"],), nl, params, 3.0, mode="shift", planned=True,
                                 r_list_max=3.4)
     assert np.array_equal(f_again, f_gpu)
+
+
+@pytest.mark.parametrize("planned", [False, True])
+def test_particle_range_launches(oracle, planned):
+    """Sub-range launches (interior first, boundary later, as the domain-decomposed
+    step does) reproduce the single full launch; untouched rows keep their values."""
+    import ctypes as C
+
+    import torch
+
+    from azplugins_amd import _lib
+
+    cfg = syn.config_plj_sc(20)
+    pos = syn.pos4(cfg["xyz"][:-3])
+    N = pos.shape[0]
+    box = oracle.make_box(cfg["L"])
+    params = oracle.pack_pair_params("PerturbedLennardJones", cfg["params"])
+    nl = oracle.build_nlist(pos, box, 3.4)
+    f_ref = oracle.pair_forces("PerturbedLennardJones", pos, box, nl, params, 3.0, nthreads=8)
+    a, t = H.gpu_pair_args(pos, (cfg["L"],), nl, 1, 3.0, 0.0, "none", False, r_list_max=3.4)
+    p = H._dev(np.atleast_2d(params))
+    lib = _lib.lib()
+    if planned:
+        plan = _lib.PairPlan()
+        plan.build(a, H._stream())
+
+        def launch():
+            _lib.check(lib.azp_pair_forces_planned_perturbed_lennard_jones(plan.handle, C.byref(a), p.data_ptr(), H._stream()))
+    else:
+        def launch():
+            _lib.check(lib.azp_pair_forces_perturbed_lennard_jones(C.byref(a), p.data_ptr(), H._stream()))
+    split = 5000
+    t["force"].fill_(7.0)
+    a.range_first, a.range_count = 0, split
+    launch()
+    torch.cuda.synchronize()
+    f1 = t["force"].cpu().numpy().copy()
+    assert_close(f1[:split], f_ref[:split])
+    tile = 256 if planned else 1
+    assert np.all(f1[((split + tile - 1) // tile) * tile:] == 7.0)  # rows beyond the (tile-rounded) range untouched
+    a.range_first, a.range_count = split, N - split
+    launch()
+    torch.cuda.synchronize()
+    assert_close(t["force"].cpu().numpy(), f_ref)
+    a.range_first, a.range_count = N - 10, 20  # out of bounds
+    rc = lib.azp_pair_forces_perturbed_lennard_jones(C.byref(a), p.data_ptr(), H._stream())
+    assert rc == -1
