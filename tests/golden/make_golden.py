@@ -56,7 +56,8 @@ def sweeps():
     for name, (r_cut, plist) in SWEEPS.items():
         r = np.linspace(SWEEP_RMIN[name], 1.05 * r_cut, 256)
         # add exact branch edges
-        r[100] = 2.0 ** (1.0 / 6.0)
+        if name == "PerturbedLennardJones":
+            r[100] = 2.0 ** (1.0 / 6.0)
         r[200] = r_cut
         res = np.zeros((len(plist), 2, 256, 3))
         for ip, p in enumerate(plist):

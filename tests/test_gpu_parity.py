@@ -507,3 +507,126 @@ def test_particle_range_launches(oracle, planned):
     a.range_first, a.range_count = N - 10, 20  # out of bounds
     rc = lib.azp_pair_forces_perturbed_lennard_jones(C.byref(a), p.data_ptr(), H._stream())
     assert rc == -1
+
+
+# ---------------------------------------------------------------------------
+# golden r-sweeps through the kernels: isolated pairs, one per sweep point
+# ---------------------------------------------------------------------------
+def _isolated_pairs(r_values, gap=40.0):
+    """2 n particles: pair k sits at y = k * gap, separated by r_k along x."""
+    n = len(r_values)
+    xyz = np.zeros((2 * n, 3))
+    xyz[0::2, 0] = -0.5 * r_values
+    xyz[1::2, 0] = 0.5 * r_values
+    xyz[0::2, 1] = xyz[1::2, 1] = (np.arange(n) - 0.5 * n) * gap
+    n_neigh = np.ones(2 * n, dtype=np.uint32)
+    head = np.arange(2 * n, dtype=np.uint64)
+    nlist = np.arange(2 * n, dtype=np.uint32) ^ 1
+    L = np.array([200.0, (n + 2) * gap, 200.0])
+    return syn.pos4(xyz), L, (n_neigh, head, nlist)
+
+
+@pytest.mark.parametrize("planned", [False, True])
+def test_golden_sweeps(oracle, planned):
+    """Every point of tests/golden/sweeps.npz (256 separations x 3 parameter sets x
+    {no shift, shift} per evaluator, incl. r = r_wca and r = r_cut exactly) as an
+    isolated pair: force_divr * r and pair_eng / 2 per particle."""
+    import importlib.util
+    import os
+
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(gdir, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    gold = np.load(os.path.join(gdir, "sweeps.npz"))
+    for name, (r_cut, plist) in mg.SWEEPS.items():
+        r = gold[name + "_r"]
+        pos, L, nl = _isolated_pairs(r)
+        for ip, p in enumerate(plist):
+            params = oracle.pack_pair_params(name, p)
+            for ish, mode in enumerate(("none", "shift")):
+                ref = gold[name][ip, ish]  # (evaluated, force_divr, energy)
+                f = H.gpu_pair_forces(name, pos, (L, (0, 0, 0), (0, 0, 0)), nl, params, r_cut, mode=mode,
+                                      planned=planned, r_list_max=1.06 * r_cut)
+                fx_expect = -ref[:, 1] * r  # particle at -r/2: dx = -r
+                scale_f = max(np.abs(fx_expect).max(), 1e-300)
+                scale_e = max(np.abs(ref[:, 2]).max(), 1e-300)
+                assert np.abs(f[0::2, 0] - fx_expect).max() <= 1e-12 * scale_f, (name, ip, mode)
+                assert np.abs(f[1::2, 0] + fx_expect).max() <= 1e-12 * scale_f, (name, ip, mode)
+                assert np.abs(f[:, 3] - 0.5 * np.repeat(ref[:, 2], 2)).max() <= 1e-12 * scale_e, (name, ip, mode)
+                assert not f[:, 1:3].any()
+                # not evaluated => exact zeros
+                off = np.repeat(ref[:, 0] == 0, 2)
+                assert not f[off].any(), (name, ip, mode)
+
+
+def test_product_nlist_matches_oracle(oracle):
+    """The GPU cell-list builder (row N1) lists exactly the oracle's pairs: per
+    type pair r_list, bonded exclusions, ghosts-free periodic box."""
+    import azplugins_amd as azp
+
+    cfg = syn.config_chains(32, 8, 8, 16)
+    n = cfg["xyz"].shape[0]
+    typeid = (np.arange(n) // 3) % 2
+    snap = azp.Snapshot.from_arrays(cfg["xyz"], cfg["L"], typeid=typeid, types=("A", "B"), bonds=cfg["bonds"])
+    sim = azp.Simulation(device="cuda:0", seed=1)
+    sim.create_state_from_snapshot(snap)
+    nl = azp.nlist.Cell(buffer=0.3)
+    pot = azp.pair.Hertz(nlist=nl, default_r_cut=2.0)
+    pot.r_cut[("A", "B")] = 1.5
+    pot.r_cut[("B", "B")] = 2.4
+    for pair in (("A", "A"), ("A", "B"), ("B", "B")):
+        pot.params[pair] = dict(epsilon=1.0)
+    sim.operations.integrator = azp.Integrator(dt=0.001, forces=[pot])
+    sim.run(0)
+    n_neigh = nl.n_neigh.cpu().numpy().astype(np.int64)
+    head = nl.head_list.cpu().numpy()
+    nlist = nl.nlist.cpu().numpy()
+    # oracle list with the same per-type-pair radii and the bonded exclusions
+    rl = np.array([[2.3, 1.8], [1.8, 2.7]])
+    n_excl = np.zeros(n, dtype=np.uint32)
+    excl = np.zeros((n, 2), dtype=np.uint32)
+    for a_, b_ in cfg["bonds"]:
+        for me, other in ((a_, b_), (b_, a_)):
+            excl[me, n_excl[me]] = other
+            n_excl[me] += 1
+    pos = syn.pos4(cfg["xyz"], typeid)
+    o_n, o_head, o_list = oracle.build_nlist(pos, oracle.make_box(cfg["L"]), rl, ntypes=2, exclusions=(n_excl, excl))
+    assert np.array_equal(n_neigh, o_n)
+    for i in range(0, n, 37):
+        mine = np.sort(nlist[head[i]: head[i] + n_neigh[i]])
+        assert np.array_equal(mine, o_list[o_head[i]: o_head[i] + o_n[i]])
+    # and the forces through the API (multi-type tables, plan or fallback) match the oracle
+    params = np.array([oracle.pack_pair_params("Hertz", dict(epsilon=1.0))] * 4)
+    rc = np.array([[2.0, 1.5], [1.5, 2.4]])
+    f_ref = oracle.pair_forces("Hertz", pos, oracle.make_box(cfg["L"]), (o_n, o_head, o_list), params, rc, ntypes=2)
+    assert_close(np.c_[pot.forces, pot.energies], f_ref)
+
+
+def test_api_virial_and_modes_multitype(oracle):
+    """hoomd.azplugins-shaped API: 3 types, xplor mode, virials, PerturbedLJ."""
+    import azplugins_amd as azp
+
+    pos, L, typeid = H.lattice_config(18, 1.1, 0.11, seed=5, ntypes=3)
+    snap = azp.Snapshot.from_arrays(pos[:, :3], L, typeid=typeid, types=("A", "B", "C"))
+    sim = azp.Simulation(device="cuda:0", seed=1)
+    sim.create_state_from_snapshot(snap)
+    nl = azp.nlist.Cell(buffer=0.3)
+    pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=2.5, default_r_on=2.0, mode="xplor")
+    pot.compute_virial = True
+    names = ("A", "B", "C")
+    tab = H.sym_table(3, PAIR_PARAMS["PerturbedLennardJones"])
+    for i in range(3):
+        for j in range(i, 3):
+            pot.params[(names[i], names[j])] = tab[i][j]
+    sim.operations.integrator = azp.Integrator(dt=0.001, forces=[pot])
+    sim.run(0)
+    params = np.array([oracle.pack_pair_params("PerturbedLennardJones", tab[i][j]) for i in range(3) for j in range(3)])
+    box = oracle.make_box(L)
+    onl = oracle.build_nlist(pos, box, 2.8, ntypes=3, half=True)
+    f_ref, v_ref = oracle.pair_forces("PerturbedLennardJones", pos, box, onl, params, 2.5, 2.0, "xplor", ntypes=3, half=True,
+                                      virial=True)
+    assert_close(np.c_[pot.forces, pot.energies], f_ref)
+    assert_close(pot.virials, v_ref.T)
+    assert pot.energy == pytest.approx(f_ref[:, 3].sum(), rel=1e-11)
+    assert pot.plan_info["valid"] == 1

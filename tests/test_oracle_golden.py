@@ -146,3 +146,23 @@ def test_dpd_alpha_symmetric_and_uniform(oracle):
     assert -1.0 < a.min() and a.max() <= 1.0
     assert abs(a.mean()) < 0.02
     assert a.var() == pytest.approx(1.0 / 3.0, rel=0.03)
+
+
+def test_oracle_reproduces_committed_sweeps(oracle):
+    """tests/golden/sweeps.npz freezes the oracle's scalar evaluators over dense
+    r-sweeps (incl. the branch edges r = r_wca, r = r_cut): a later edit of the
+    oracle cannot silently move the target."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    gold = np.load(os.path.join(GOLDEN, "sweeps.npz"))
+    for name, (r_cut, plist) in mg.SWEEPS.items():
+        r = gold[name + "_r"]
+        ref = gold[name]
+        for ip, p in enumerate(plist):
+            for ish, sh in enumerate((False, True)):
+                for ir in range(0, len(r), 7):
+                    ok, f, e = oracle.eval_pair(name, p, float(r[ir]), r_cut, sh)
+                    assert (float(ok), f, e) == tuple(ref[ip, ish, ir])
