@@ -48,10 +48,25 @@ class Cell(NeighborList):
     """Cell-list neighbor list (full storage, as HOOMD's GPU pair kernels use)."""
 
     def compute(self, state, force=False):
-        if not force and self._built_generation == state.position_generation and self.nlist is not None:
-            return
+        """Rebuild only when needed (HOOMD's criterion): never built, forced, or some
+        particle moved farther than buffer / 2 since the last build."""
+        if not force and self.nlist is not None:
+            if self._built_generation == state.position_generation:
+                return
+            if self._max_displacement(state) <= 0.5 * self.buffer:
+                self._built_generation = state.position_generation
+                return
         self._build(state)
         self._built_generation = state.position_generation
+
+    def _max_displacement(self, state):
+        import torch
+
+        d = state.pos[: state.n_max, :3] - self._pos_at_build
+        L = torch.tensor(state.box.L, dtype=d.dtype, device=d.device)
+        per = torch.tensor([1.0 if p else 0.0 for p in state.box.periodic], dtype=d.dtype, device=d.device)
+        d = d - per * L * torch.round(d / L)
+        return float((d * d).sum(dim=1).max().sqrt().item())
 
     def _build(self, state):
         import torch
@@ -124,5 +139,6 @@ class Cell(NeighborList):
         _lib.check(l.azp_nlist_fill(C.byref(a), stream), "azp_nlist_fill")
 
         self.n_neigh, self.head_list, self.nlist, self.size = n_neigh, head, nlist, size
+        self._pos_at_build = state.pos[:n_total, :3].clone()
         self.num_builds += 1
         self._keep = (rlistsq, cell_of, cell_sorted, order, cell_start, keep)

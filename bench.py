@@ -60,6 +60,24 @@ def measured_traffic(kernel, workload):
     return None, None
 
 
+def displace_particles(state, amplitude, seed):
+    """Move every local particle by a hashed random vector (uniform direction, length
+    uniform in [0, amplitude]) and wrap it back into the box: the state of an MD run
+    part-way between two neighbor-list rebuilds."""
+    import torch
+
+    from azplugins_amd import synthetic as syn
+
+    n = state.N
+    tag = np.arange(n, dtype=np.uint64)
+    v = np.stack([syn.normal(seed, tag, c) for c in range(3)], axis=1)
+    v *= (amplitude * syn.u01(seed, tag, 7) / np.linalg.norm(v, axis=1))[:, None]
+    x = state.pos[:n, :3].cpu().numpy() + v
+    x = syn.wrap(x, state.box.L)
+    state.pos[:n, :3] = torch.from_numpy(x).to(state.pos.device)
+    state.position_generation += 1
+
+
 def cpu_baseline(workload, reps=5):
     """HOOMD-equivalent CPU loop restated (oracle): half neighbor list, third-law
     scatter, FP64, ONE core (HOOMD's per-rank CPU execution model), timed on
@@ -112,6 +130,10 @@ def main():
     ap.add_argument("--no-plan", action="store_true", help="generic kernel only (no LDS-staged tile plan)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1 GPUs: weak = 2^20 particles per GPU (default), strong = 2^20 in total")
+    ap.add_argument("--displace", type=float, default=0.0,
+                    help="sensitivity run: after the neighbor list and plan are built, move every particle by a hashed "
+                         "random vector of length <= DISPLACE * r_buff / 2 (0 = the snapshot the list was built for, as "
+                         "the metric is defined; 1 = the moment before the next rebuild)")
     ap.add_argument("--sort-rows", action="store_true", help="experiment: sort every neighbor row by index before planning")
     args = ap.parse_args()
 
@@ -156,6 +178,10 @@ def main():
         del row, key
         pot.compute(0)
     mean_neigh = nl.size / N
+    if args.displace > 0.0:
+        displace_particles(sim.state, args.displace * 0.5 * cfg["r_buff"], seed=11)
+        pot.compute(0)
+        assert nl.num_builds == 1, "the displacement must not trigger a neighbor-list rebuild"
 
     for _ in range(args.warmup):
         pot.compute(0)
@@ -198,6 +224,8 @@ def main():
                                                         "FCC" if args.workload.startswith("ns") else "SC", mean_neigh),
             "N": N,
             "mean_neighbors": mean_neigh,
+            "displacement_since_list_build": "every particle moved by <= %.3g (= %.2f x r_buff/2)"
+                                             % (args.displace * 0.5 * cfg["r_buff"], args.displace),
             "launch": launch,
             "tile_plan": pot.plan_info,
             "parallelism": "1 GPU",
