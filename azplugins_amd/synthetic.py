@@ -167,8 +167,7 @@ def config_north_star(ncell=64, seed=3):
 
 def config_chains(nx=128, ny=128, nz=64, chain_len=32, seed=4):
     """Linear chains laid along x on a simple-cubic lattice (configs[2] at the
-    default size: 32,768 chains of 32 beads). Particles stay in lattice
-    (x-fastest) order so that a chain is contiguous in index."""
+    default size: 32,768 chains of 32 beads), particles in blocked spatial order."""
     a = 0.8 ** (-1.0 / 3.0)
     assert nx % chain_len == 0
     L = np.array([nx * a, ny * a, nz * a])
@@ -181,7 +180,17 @@ def config_chains(nx=128, ny=128, nz=64, chain_len=32, seed=4):
     xyz = wrap(xyz + _jitter(seed, n, 0.05 * a), L)
     idx = np.arange(n)
     first = idx[(ix % chain_len) != (chain_len - 1)]
-    bonds = np.stack([first, first + 1], axis=1).astype(np.uint32)
+    bonds = np.stack([first, first + 1], axis=1)
+    # HOOMD's SFC sorter reorders particles in memory regardless of chain
+    # membership (bonds follow through the tag lookup): emit the particles in the
+    # same blocked spatial order as the other configurations and remap the bonds
+    key = (((iz // 4) * ((ny + 3) // 4) + (iy // 4)) * ((nx + 3) // 4) + (ix // 4)).astype(np.int64)
+    inner = ((iz % 4) * 4 + (iy % 4)) * 4 + (ix % 4)
+    perm = np.lexsort((inner, key))          # new position -> old index
+    inv = np.empty(n, dtype=np.int64)
+    inv[perm] = np.arange(n)
+    xyz = xyz[perm]
+    bonds = inv[bonds].astype(np.uint32)
     return dict(name="C3", xyz=xyz, L=L, bonds=bonds, potential="PerturbedLennardJones",
                 params=dict(epsilon=1.0, sigma=1.0, attraction_scale_factor=0.5), r_cut=3.0, r_buff=0.4,
                 bond_potential="DoubleWell", bond_params=dict(r_0=1.0, r_1=1.5, U_1=1.0, U_tilt=0.5))
