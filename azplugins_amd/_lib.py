@@ -87,6 +87,35 @@ class BondArgs(C.Structure):
     ]
 
 
+class BarrierArgs(C.Structure):
+    _fields_ = [
+        ("d_force", C.c_void_p),
+        ("d_virial", C.c_void_p),
+        ("virial_pitch", C.c_uint64),
+        ("N", C.c_uint32),
+        ("ntypes", C.c_uint32),
+        ("d_pos", C.c_void_p),
+        ("box", Box),
+        ("d_params", C.c_void_p),
+        ("location", C.c_double),
+        ("block_size", C.c_uint32),
+        ("_pad", C.c_uint32),
+    ]
+
+
+class NVEArgs(C.Structure):
+    _fields_ = [
+        ("d_pos", C.c_void_p),
+        ("d_vel", C.c_void_p),
+        ("d_net_force", C.c_void_p),
+        ("d_image", C.c_void_p),
+        ("box", Box),
+        ("dt", C.c_double),
+        ("N", C.c_uint32),
+        ("block_size", C.c_uint32),
+    ]
+
+
 class PlanInfo(C.Structure):
     _fields_ = [
         ("valid", C.c_int32),
@@ -168,6 +197,12 @@ SYMBOLS = {
     "azp_nlist_cell_bounds": (C.c_int, [C.POINTER(NlistArgs), _VP]),
     "azp_nlist_count": (C.c_int, [C.POINTER(NlistArgs), _VP]),
     "azp_nlist_fill": (C.c_int, [C.POINTER(NlistArgs), _VP]),
+    "azp_external_planar_harmonic_barrier": (C.c_int, [C.POINTER(BarrierArgs), _VP]),
+    "azp_external_spherical_harmonic_barrier": (C.c_int, [C.POINTER(BarrierArgs), _VP]),
+    "azp_planar_barrier_valid": (C.c_int, [_D, C.POINTER(Box)]),
+    "azp_spherical_barrier_valid": (C.c_int, [_D, C.POINTER(Box)]),
+    "azp_integrate_nve_step_one": (C.c_int, [C.POINTER(NVEArgs), _VP]),
+    "azp_integrate_nve_step_two": (C.c_int, [C.POINTER(NVEArgs), _VP]),
     "azp_version": (C.c_int, []),
     "azp_status_string": (C.c_char_p, [C.c_int]),
     "azp_last_launch": (None, [C.POINTER(C.c_uint32)] * 4),

@@ -1,0 +1,232 @@
+// external_forces.hip -- one-body harmonic barrier forces:
+// planar (src/PlanarBarrierEvaluator.h:36-48) and spherical
+// (src/SphericalBarrierEvaluator.h:36-51) evaluators inside the loop of
+// src/HarmonicBarrier.h:150-177 / src/HarmonicBarrierGPU.cuh:49-84.
+// Pure streaming: 32 B in, 32 B out per particle, one lane per particle,
+// per-type (k, offset) pairs in LDS.
+#include "azp_device.hpp"
+#include "pair_kernel_host.hpp"
+
+namespace azp
+{
+struct BarrierKArgs
+    {
+    double* force;
+    const double* pos;
+    const double* params;
+    BoxDev box;
+    double location;
+    uint32_t N;
+    uint32_t ntypes;
+    };
+
+// HOOMD BoxDim::wrap restated for one shift per axis (particles drift by much
+// less than a box length between wraps)
+__device__ __forceinline__ void wrap_into_box(const BoxDev& b, double& x, double& y, double& z)
+    {
+    if (b.pz)
+        {
+        const double h = 0.5 * b.Lz;
+        if (z >= h) { z -= b.Lz; y -= b.Lz * b.yz; x -= b.Lz * b.xz; }
+        else if (z < -h) { z += b.Lz; y += b.Lz * b.yz; x += b.Lz * b.xz; }
+        }
+    if (b.py)
+        {
+        const double h = 0.5 * b.Ly, s = z * b.yz;
+        if (y >= h + s) { y -= b.Ly; x -= b.Ly * b.xy; }
+        else if (y < -h + s) { y += b.Ly; x += b.Ly * b.xy; }
+        }
+    if (b.px)
+        {
+        const double h = 0.5 * b.Lx, s = y * b.xy + z * (b.xz - b.xy * b.yz);
+        if (x >= h + s) x -= b.Lx;
+        else if (x < -h + s) x += b.Lx;
+        }
+    }
+
+template<bool SPHERICAL> __global__ void __launch_bounds__(256) barrier_kernel(const BarrierKArgs a)
+    {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    double2* s_params = reinterpret_cast<double2*>(s_raw);
+    for (uint32_t t = threadIdx.x; t < a.ntypes; t += blockDim.x)
+        s_params[t] = make_double2(a.params[2 * t], a.params[2 * t + 1]);
+    __syncthreads();
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.N)
+        return;
+    const double4 p = load_scalar4(a.pos, idx);
+    double x = p.x, y = p.y, z = p.z;
+    wrap_into_box(a.box, x, y, z);
+    const double2 prm = s_params[type_from_w(p.w)];
+    double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0;
+    if (SPHERICAL)
+        {
+        const double r = sqrt(x * x + y * y + z * z);
+        const double dr = r - (a.location + prm.y);
+        if (dr > 0.0)
+            {
+            const double k_dr = prm.x * dr;
+            const double s = -(k_dr / r);
+            fx = s * x; fy = s * y; fz = s * z;
+            e = 0.5 * k_dr * dr;
+            }
+        }
+    else
+        {
+        const double dy = y - (a.location + prm.y);
+        if (dy > 0.0)
+            {
+            fy = -prm.x * dy;
+            e = -0.5 * fy * dy;
+            }
+        }
+    store_scalar4(a.force, idx, fx, fy, fz, e);
+    }
+
+template<bool SPHERICAL> static int launch_barrier(const azp_barrier_args* args, void* stream)
+    {
+    if (!args)
+        return AZP_ERROR_INVALID_ARGUMENT;
+    if (args->N == 0)
+        return AZP_SUCCESS;
+    if (!args->d_force || !args->d_pos || !args->d_params || args->ntypes == 0)
+        return AZP_ERROR_INVALID_ARGUMENT;
+    const uint32_t bs = args->block_size ? args->block_size : 256u;
+    if (bs % 64 || bs > 256)
+        return AZP_ERROR_INVALID_ARGUMENT;
+    const size_t lds = sizeof(double2) * (size_t)args->ntypes;
+    if (lds > 64 * 1024)
+        return AZP_ERROR_TOO_MANY_TYPES;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (args->d_virial)
+        {
+        // the reference sets the virial to zero (src/HarmonicBarrier.h:179-180)
+        hipError_t e = hipMemsetAsync(args->d_virial, 0, sizeof(double) * 6 * args->virial_pitch, s);
+        if (e != hipSuccess)
+            return (int)e;
+        }
+    BarrierKArgs k;
+    k.force = args->d_force;
+    k.pos = args->d_pos;
+    k.params = args->d_params;
+    k.box = make_box_dev(args->box);
+    k.location = args->location;
+    k.N = args->N;
+    k.ntypes = args->ntypes;
+    const uint32_t grid = (args->N + bs - 1) / bs;
+    LaunchInfo& li = last_launch();
+    li.block_size = bs; li.tpp = 1; li.grid = grid; li.lds_bytes = (uint32_t)lds;
+    hipLaunchKernelGGL(barrier_kernel<SPHERICAL>, dim3(grid), dim3(bs), lds, s, k);
+    return (int)hipGetLastError();
+    }
+
+// ---------------------------------------------------------------------------
+// velocity-Verlet NVE
+// ---------------------------------------------------------------------------
+struct NVEKArgs
+    {
+    double* pos;
+    double* vel;
+    const double* net_force;
+    int32_t* image;
+    BoxDev box;
+    double dt;
+    uint32_t N;
+    };
+
+template<bool STEP_ONE> __global__ void __launch_bounds__(256) nve_kernel(const NVEKArgs a)
+    {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.N)
+        return;
+    double4 v = load_scalar4(a.vel, idx);
+    const double4 f = load_scalar4(a.net_force, idx);
+    const double minv = 1.0 / v.w;
+    const double hdt = 0.5 * a.dt;
+    v.x += hdt * f.x * minv; v.y += hdt * f.y * minv; v.z += hdt * f.z * minv;
+    store_scalar4(a.vel, idx, v.x, v.y, v.z, v.w);
+    if (STEP_ONE)
+        {
+        const double4 p = load_scalar4(a.pos, idx);
+        double x = p.x + a.dt * v.x, y = p.y + a.dt * v.y, z = p.z + a.dt * v.z;
+        const double x0 = x, y0 = y, z0 = z;
+        wrap_into_box(a.box, x, y, z);
+        store_scalar4(a.pos, idx, x, y, z, p.w);
+        if (a.image)
+            {
+            // which way was it wrapped (orthorhombic shortcut is exact; for triclinic
+            // boxes the z shift is read off z, the y shift off y after removing z's tilt)
+            const int iz = (z < z0) - (z > z0);
+            const double y1 = y0 - iz * a.box.Lz * a.box.yz;
+            const int iy = (y < y1) - (y > y1);
+            const double x1 = x0 - iz * a.box.Lz * a.box.xz - iy * a.box.Ly * a.box.xy;
+            const int ix = (x < x1) - (x > x1);
+            a.image[3 * idx + 0] += ix; a.image[3 * idx + 1] += iy; a.image[3 * idx + 2] += iz;
+            }
+        }
+    }
+
+template<bool STEP_ONE> static int launch_nve(const azp_nve_args* args, void* stream)
+    {
+    if (!args)
+        return AZP_ERROR_INVALID_ARGUMENT;
+    if (args->N == 0)
+        return AZP_SUCCESS;
+    if (!args->d_pos || !args->d_vel || !args->d_net_force)
+        return AZP_ERROR_INVALID_ARGUMENT;
+    const uint32_t bs = args->block_size ? args->block_size : 256u;
+    if (bs % 64 || bs > 256)
+        return AZP_ERROR_INVALID_ARGUMENT;
+    NVEKArgs k;
+    k.pos = args->d_pos;
+    k.vel = args->d_vel;
+    k.net_force = args->d_net_force;
+    k.image = args->d_image;
+    k.box = make_box_dev(args->box);
+    k.dt = args->dt;
+    k.N = args->N;
+    const uint32_t grid = (args->N + bs - 1) / bs;
+    hipLaunchKernelGGL(nve_kernel<STEP_ONE>, dim3(grid), dim3(bs), 0, static_cast<hipStream_t>(stream), k);
+    return (int)hipGetLastError();
+    }
+} // namespace azp
+
+extern "C" int azp_external_planar_harmonic_barrier(const azp_barrier_args* args, void* stream)
+    {
+    return azp::launch_barrier<false>(args, stream);
+    }
+extern "C" int azp_external_spherical_harmonic_barrier(const azp_barrier_args* args, void* stream)
+    {
+    return azp::launch_barrier<true>(args, stream);
+    }
+extern "C" int azp_integrate_nve_step_one(const azp_nve_args* args, void* stream)
+    {
+    return azp::launch_nve<true>(args, stream);
+    }
+extern "C" int azp_integrate_nve_step_two(const azp_nve_args* args, void* stream)
+    {
+    return azp::launch_nve<false>(args, stream);
+    }
+
+// src/PlanarBarrierEvaluator.h:50-55: H inside [lo.y, hi.y) of the box
+extern "C" int azp_planar_barrier_valid(double H, const azp_box* box)
+    {
+    if (!box)
+        return 0;
+    const double lo = -0.5 * box->L[1], hi = 0.5 * box->L[1];
+    return (H >= lo && H < hi) ? 1 : 0;
+    }
+// src/SphericalBarrierEvaluator.h:53-59: R >= 0 and 2 R <= nearest plane distance
+extern "C" int azp_spherical_barrier_valid(double R, const azp_box* box)
+    {
+    if (!box)
+        return 0;
+    // nearest plane distances of a triclinic box (HOOMD BoxDim::getNearestPlaneDistance)
+    const double xy = box->tilt[0], xz = box->tilt[1], yz = box->tilt[2];
+    const double term = xy * yz - xz;
+    const double dx = box->L[0] / sqrt(1.0 + xy * xy + term * term);
+    const double dy = box->L[1] / sqrt(1.0 + yz * yz);
+    const double dz = box->L[2];
+    const double two_R = 2.0 * R;
+    return (R >= 0.0 && dx >= two_R && dy >= two_R && dz >= two_R) ? 1 : 0;
+    }

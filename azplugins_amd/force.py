@@ -62,8 +62,12 @@ class TypeParameter:
         if self._readback is not None:
             rb = self._readback(k)
             if rb is not None:
-                return rb
-        return dict(self._data[k]) if isinstance(self._data[k], dict) else self._data[k]
+                return _ParamView(self, k, rb)
+        if k not in self._data:
+            # HOOMD hands out a (partially filled) dict for a type that has no
+            # parameters yet, e.g. ``barrier.params["A"].update(...)``
+            return _ParamView(self, k, {})
+        return _ParamView(self, k, self._data[k]) if isinstance(self._data[k], dict) else self._data[k]
 
     def __contains__(self, key):
         return self._key(key) in self._data
@@ -73,6 +77,25 @@ class TypeParameter:
 
     def get_raw(self, key, default=None):
         return self._data.get(self._key(key), default)
+
+
+class _ParamView(dict):
+    """dict returned by ``params[key]``; ``update`` / item assignment write through
+    (with validation), as HOOMD's TypeParameterDict entries do."""
+
+    def __init__(self, owner, key, values):
+        super().__init__(values)
+        self._owner = owner
+        self._key_ = key
+
+    def update(self, *args, **kwargs):
+        merged = dict(self)
+        merged.update(*args, **kwargs)
+        self._owner[self._key_] = merged
+        super().update(self._owner._data[self._owner._key(self._key_)])
+
+    def __setitem__(self, k, v):
+        self.update({k: v})
 
 
 class ScalarTypeParameter(TypeParameter):

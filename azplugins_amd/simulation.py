@@ -87,19 +87,25 @@ class Simulation:
         self._compute_forces()
         if steps == 0 or not integ.methods:
             return
-        dt = integ.dt
-        L = torch.tensor(st.box.L, dtype=torch.float64, device=st.device)
+        import ctypes as C
+
+        a = _lib.NVEArgs()
+        a.d_pos = st.pos.data_ptr()
+        a.d_vel = st.vel.data_ptr()
+        a.d_net_force = st.net_force.data_ptr()
+        a.d_image = st.image.data_ptr()
+        a.box = st.box.to_c()
+        a.dt = integ.dt
+        a.N = st.N
+        lib = _lib.lib()
+        stream = torch.cuda.current_stream(st.device).cuda_stream
         for _ in range(steps):
-            # velocity Verlet, first half: v += a dt/2 ; x += v dt ; wrap
-            m = st.vel[: st.N, 3:4]
-            st.vel[: st.N, :3] += 0.5 * dt * st.net_force[:, :3] / m
-            x = st.pos[: st.N, :3] + dt * st.vel[: st.N, :3]
-            x = x - L * torch.floor(x / L + 0.5)
-            st.pos[: st.N, :3] = x
+            # velocity Verlet (libazp kernels): v += a dt/2, x += v dt, wrap | forces | v += a dt/2
+            _lib.check(lib.azp_integrate_nve_step_one(C.byref(a), stream), "azp_integrate_nve_step_one")
             st.position_generation += 1
             self.timestep += 1
             self._compute_forces()
-            st.vel[: st.N, :3] += 0.5 * dt * st.net_force[:, :3] / m
+            _lib.check(lib.azp_integrate_nve_step_two(C.byref(a), stream), "azp_integrate_nve_step_two")
 
     def kinetic_temperature(self):
         """Instantaneous kT = 2 KE / (3 N - 3) (HOOMD ThermodynamicQuantities)."""

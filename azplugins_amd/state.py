@@ -199,6 +199,7 @@ class State:
         self.orientation = torch.from_numpy(np.ascontiguousarray(p.orientation, dtype=np.float64)).to(self.device)
         self.tag = torch.from_numpy(np.ascontiguousarray(p.tag, dtype=np.uint32).view(np.int32)).to(self.device)
         self.net_force = torch.zeros((self.N, 4), dtype=f64, device=self.device)
+        self.image = torch.zeros((p.N, 3), dtype=torch.int32, device=self.device)
         b = snapshot.bonds
         self.bond_types = list(b.types)
         self.bond_group = np.ascontiguousarray(b.group, dtype=np.uint32).reshape(-1, 2)

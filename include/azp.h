@@ -302,6 +302,57 @@ int azp_nlist_cell_bounds(const azp_nlist_args* args, void* stream);
 int azp_nlist_count(const azp_nlist_args* args, void* stream);
 int azp_nlist_fill(const azp_nlist_args* args, void* stream);
 
+/* ---- one-body harmonic barriers ----
+ * Replaces the reference's own kernel driver
+ *   azplugins::gpu::compute_harmonic_barrier<Evaluator>(...)   (src/HarmonicBarrierGPU.cuh:49-140,
+ *   instantiated at src/HarmonicBarrierGPUKernel.cu.inc) for PlanarBarrierEvaluator
+ *   (src/PlanarBarrierEvaluator.h:36-48) and SphericalBarrierEvaluator
+ *   (src/SphericalBarrierEvaluator.h:36-51).
+ * d_params: one (k, offset) pair per particle type (HOOMD Scalar2). Positions are
+ * wrapped into the box before evaluation (src/HarmonicBarrier.h:167-169). The
+ * virial is not computed by the reference (set to zero there); d_virial may be NULL. */
+typedef struct azp_barrier_args
+    {
+    double* d_force;      /* N x 4, overwritten */
+    double* d_virial;     /* 6 x virial_pitch, zeroed if not NULL */
+    uint64_t virial_pitch;
+    uint32_t N;
+    uint32_t ntypes;
+    const double* d_pos;  /* N x 4 */
+    azp_box box;
+    const double* d_params; /* ntypes x 2: k, offset */
+    double location;      /* H (planar: y position) or R (spherical: radius) at this timestep */
+    uint32_t block_size;
+    uint32_t _pad;
+    } azp_barrier_args;
+
+int azp_external_planar_harmonic_barrier(const azp_barrier_args* args, void* stream);
+int azp_external_spherical_harmonic_barrier(const azp_barrier_args* args, void* stream);
+/* host-side validity checks of the evaluators (PlanarBarrierEvaluator::valid,
+ * SphericalBarrierEvaluator::valid): 1 valid, 0 invalid */
+int azp_planar_barrier_valid(double H, const azp_box* box);
+int azp_spherical_barrier_valid(double R, const azp_box* box);
+
+/* ---- velocity-Verlet NVE step ----
+ * HOOMD's hoomd.md.methods.ConstantVolume without thermostat (the dummy
+ * integrator of every reference test, src/pytest/test_pair.py:325-327), restated:
+ * step one: v += a dt/2, x += v dt, wrap into the box (image counters updated);
+ * step two: v += a dt/2 with the new net force. a = F / m, m = vel.w. */
+typedef struct azp_nve_args
+    {
+    double* d_pos;            /* N x 4 (type in w is preserved) */
+    double* d_vel;            /* N x 4 (vx, vy, vz, mass) */
+    const double* d_net_force; /* N x 4 */
+    int32_t* d_image;         /* N x 3 periodic image counters, may be NULL */
+    azp_box box;
+    double dt;
+    uint32_t N;
+    uint32_t block_size;
+    } azp_nve_args;
+
+int azp_integrate_nve_step_one(const azp_nve_args* args, void* stream);
+int azp_integrate_nve_step_two(const azp_nve_args* args, void* stream);
+
 /* ---- misc ---- */
 int azp_version(void);                    /* major * 1000 + minor       */
 const char* azp_status_string(int status);

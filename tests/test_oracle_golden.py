@@ -166,3 +166,18 @@ def test_oracle_reproduces_committed_sweeps(oracle):
                 for ir in range(0, len(r), 7):
                     ok, f, e = oracle.eval_pair(name, p, float(r[ir]), r_cut, sh)
                     assert (float(ok), f, e) == tuple(ref[ip, ish, ir])
+
+
+@pytest.mark.parametrize("kind", ["spherical", "planar"])
+def test_external_barrier_known_answers(oracle, kind):
+    """src/pytest/test_external.py:95-223 against the oracle's barrier loop."""
+    ext = CASES["external"]
+    c = ext[kind]
+    pos = oracle.pos4(np.array(c["positions"], dtype=float), ext["typeid"])
+    box = oracle.make_box(ext["box"])
+    for run in ("run1", "run2"):
+        r = c[run]
+        params = [[ext["kA"], ext["offset_A"]], [r["kB"], ext["offset_B"]]]
+        f = oracle.barrier_forces(kind, pos, box, params, r["location"])
+        np.testing.assert_allclose(f[:, 3], r["energies"], atol=1e-4)
+        np.testing.assert_allclose(f[:, :3], r["forces"], atol=1e-4)
