@@ -156,6 +156,9 @@ class NlistArgs(C.Structure):
         ("d_n_neigh", C.c_void_p),
         ("d_head_list", C.c_void_p),
         ("d_nlist", C.c_void_p),
+        ("row_capacity", C.c_uint32),
+        ("_pad2", C.c_uint32),
+        ("d_max_neigh", C.c_void_p),
     ]
 
 

@@ -79,78 +79,227 @@ struct NlistKArgs
     uint32_t* n_neigh;
     const uint64_t* head_list;
     uint32_t* nlist;
+    uint32_t* max_neigh;
+    uint32_t row_capacity;
     BoxDev box;
     GridDev grid;
     uint32_t N;
     uint32_t ntypes;
     };
 
-// FILL = false: count neighbors; FILL = true: write them at head_list[i].
-template<bool FILL> __global__ void __launch_bounds__(256) nlist_scan_kernel(const NlistKArgs a)
-    {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.N)
-        return;
-    const double4 pi = load_scalar4(a.pos, i);
-    const int typei = type_from_w(pi.w);
-    const uint32_t ci = a.cell_of[i];
-    const int cx = ci % a.grid.dim[0], cy = (ci / a.grid.dim[0]) % a.grid.dim[1], cz = ci / (a.grid.dim[0] * a.grid.dim[1]);
-    const uint32_t nex = a.n_excl ? a.n_excl[i] : 0u;
-    uint32_t count = 0;
-    uint32_t* out = FILL ? a.nlist + a.head_list[i] : nullptr;
+// ---------------------------------------------------------------------------
+// Count / fill, one workgroup per cell.
+//
+// All particles of a cell share the same <= 27 candidate cells, so the workgroup
+// stages those candidates once in LDS (positions as the image nearest to the cell
+// centre, original index, type) with contiguous reads of the cell-sorted order,
+// and each wave then takes one home particle at a time: the 64 lanes test 64
+// consecutive staged candidates (conflict-free LDS reads), a ballot compacts the
+// accepted ones, and the row is written as contiguous runs -- the list is
+// streamed out once instead of with scattered 4-byte stores.
+// FILL = false: count; FILL = true: write rows at head_list[i].
+// MI = true: per-pair minimum image (boxes with < 4 cells along a periodic axis,
+// triclinic boxes); MI = false: images resolved once per staged candidate.
+// Dense cells are handled in batches of NL_CAP candidates x NL_HOME home particles.
+// ---------------------------------------------------------------------------
+constexpr uint32_t NL_CAP = 1280;
+constexpr uint32_t NL_HOME = 1024;
+constexpr uint32_t NL_THREADS = 512;
+constexpr uint32_t NL_WAVES = NL_THREADS / 64;
+constexpr uint32_t NL_PAD_IDX = 0xffffffffu;
 
-    // offset ranges per axis: a periodic axis with fewer than 3 cells must not
-    // visit the same cell twice
-    int lo[3], hi[3];
-    for (int k = 0; k < 3; ++k)
+struct NlStencil
+    {
+    uint32_t first[27];
+    uint32_t off[28];
+    };
+
+template<bool FILL, bool MI> __global__ void __launch_bounds__(NL_THREADS) nlist_cell_kernel(const NlistKArgs a, uint32_t ncell,
+                                                                                      uint32_t nblocks_pad8)
+    {
+    __shared__ double sx[NL_CAP + 128], sy[NL_CAP + 128], sz[NL_CAP + 128];
+    __shared__ uint32_t sidx[NL_CAP + 128], styp[NL_CAP + 128];
+    __shared__ uint32_t run[NL_HOME];
+    __shared__ NlStencil st;
+
+    const uint32_t cell = xcd_remap(blockIdx.x, nblocks_pad8);
+    if (cell >= ncell)
+        return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const int dimx = a.grid.dim[0], dimy = a.grid.dim[1];
+    const int cx = cell % dimx, cy = (cell / dimx) % dimy, cz = cell / (dimx * dimy);
+    const uint32_t hs = a.cell_start[cell], nhome = a.cell_start[cell + 1] - hs;
+    if (nhome == 0)
+        return;
+
+    if (tid < 27)
         {
-        const int d = a.grid.dim[k];
-        if (a.grid.periodic[k] && d < 3) { lo[k] = 0; hi[k] = d - 1; }
-        else { lo[k] = -1; hi[k] = 1; }
-        }
-    for (int oz = lo[2]; oz <= hi[2]; ++oz)
-        {
-        int nz = cz + oz;
-        if (a.grid.periodic[2]) nz = (nz + a.grid.dim[2]) % a.grid.dim[2];
-        else if (nz < 0 || nz >= a.grid.dim[2]) continue;
-        for (int oy = lo[1]; oy <= hi[1]; ++oy)
+        const int o[3] = {(int)(tid % 3) - 1, (int)((tid / 3) % 3) - 1, (int)(tid / 9) - 1};
+        const int c[3] = {cx, cy, cz};
+        int n[3];
+        bool valid = true;
+        for (int k = 0; k < 3; ++k)
             {
-            int ny = cy + oy;
-            if (a.grid.periodic[1]) ny = (ny + a.grid.dim[1]) % a.grid.dim[1];
-            else if (ny < 0 || ny >= a.grid.dim[1]) continue;
-            for (int ox = lo[0]; ox <= hi[0]; ++ox)
+            const int d = a.grid.dim[k];
+            if (a.grid.periodic[k])
                 {
-                int nx = cx + ox;
-                if (a.grid.periodic[0]) nx = (nx + a.grid.dim[0]) % a.grid.dim[0];
-                else if (nx < 0 || nx >= a.grid.dim[0]) continue;
-                const uint32_t nc = (uint32_t)((nz * a.grid.dim[1] + ny) * a.grid.dim[0] + nx);
-                const uint32_t qb = a.cell_start[nc], qe = a.cell_start[nc + 1];
-                for (uint32_t q = qb; q < qe; ++q)
+                if (d < 3)
                     {
-                    const uint32_t j = a.order[q];
-                    if (j == i)
-                        continue;
-                    const double4 pj = load_scalar4(a.pos, j);
-                    double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-                    min_image(a.box, dx, dy, dz);
-                    const double rsq = dx * dx + dy * dy + dz * dz;
-                    const double rl = a.rlistsq[(uint32_t)typei * a.ntypes + (uint32_t)type_from_w(pj.w)];
-                    if (rl <= 0.0 || rsq > rl)
-                        continue;
-                    bool excluded = false;
-                    for (uint32_t e = 0; e < nex; ++e)
-                        excluded |= (a.excl[(uint64_t)e * a.excl_pitch + i] == j);
-                    if (excluded)
-                        continue;
-                    if (FILL)
-                        out[count] = j;
-                    ++count;
+                    // fewer than 3 cells: visit each cell of the axis exactly once
+                    n[k] = o[k] + 1;
+                    valid &= n[k] < d;
                     }
+                else
+                    n[k] = (c[k] + o[k] + d) % d;
+                }
+            else
+                {
+                n[k] = c[k] + o[k];
+                valid &= (n[k] >= 0 && n[k] < d);
                 }
             }
+        uint32_t first = 0, cnt = 0;
+        if (valid)
+            {
+            const uint32_t nc = (uint32_t)((n[2] * dimy + n[1]) * dimx + n[0]);
+            first = a.cell_start[nc];
+            cnt = a.cell_start[nc + 1] - first;
+            }
+        st.first[tid] = first;
+        st.off[tid + 1] = cnt;
         }
-    if (!FILL)
-        a.n_neigh[i] = count;
+    __syncthreads();
+    if (tid == 0)
+        {
+        uint32_t acc = 0;
+        st.off[0] = 0;
+        for (int s = 1; s <= 27; ++s)
+            {
+            acc += st.off[s];
+            st.off[s] = acc;
+            }
+        }
+    __syncthreads();
+    const uint32_t total = st.off[27];
+
+    // cell centre: reference point of the staged images
+    const double ccx = a.grid.lo[0] + (cx + 0.5) / a.grid.winv[0];
+    const double ccy = a.grid.lo[1] + (cy + 0.5) / a.grid.winv[1];
+    const double ccz = a.grid.lo[2] + (cz + 0.5) / a.grid.winv[2];
+    const double rl_single = a.rlistsq[0];
+    const bool one_type = (a.ntypes == 1);
+
+    for (uint32_t hc = 0; hc < nhome; hc += NL_HOME)
+        {
+        const uint32_t nh = min(NL_HOME, nhome - hc);
+        for (uint32_t t = tid; t < nh; t += NL_THREADS)
+            run[t] = 0;
+        for (uint32_t b0 = 0; b0 < total; b0 += NL_CAP)
+            {
+            const uint32_t nb = min(NL_CAP, total - b0);
+            __syncthreads(); // previous batch fully consumed (and run[] zeroed)
+            // pad to a multiple of 128 so that the test loop needs no bounds checks
+            const uint32_t nb_pad = (nb + 127u) & ~127u;
+            for (uint32_t t = nb + tid; t < nb_pad; t += NL_THREADS)
+                {
+                sx[t] = 1e150; sy[t] = 1e150; sz[t] = 1e150;
+                sidx[t] = NL_PAD_IDX;
+                styp[t] = 0;
+                }
+            for (uint32_t t = tid; t < nb; t += NL_THREADS)
+                {
+                const uint32_t g = b0 + t;
+                int s = 0;
+                while (g >= st.off[s + 1])
+                    ++s;
+                const uint32_t j = a.order[st.first[s] + (g - st.off[s])];
+                const double4 pj = load_scalar4(a.pos, j);
+                double x = pj.x, y = pj.y, z = pj.z;
+                if (!MI)
+                    {
+                    if (a.box.px) x = __builtin_fma(-a.box.Lx, rint((x - ccx) * a.box.Lxinv), x);
+                    if (a.box.py) y = __builtin_fma(-a.box.Ly, rint((y - ccy) * a.box.Lyinv), y);
+                    if (a.box.pz) z = __builtin_fma(-a.box.Lz, rint((z - ccz) * a.box.Lzinv), z);
+                    }
+                sx[t] = x; sy[t] = y; sz[t] = z;
+                sidx[t] = j;
+                styp[t] = (uint32_t)type_from_w(pj.w);
+                }
+            __syncthreads();
+
+            for (uint32_t h = wave; h < nh; h += NL_WAVES)
+                {
+                const uint32_t i = __builtin_amdgcn_readfirstlane(a.order[hs + hc + h]);
+                if (i >= a.N)
+                    continue; // ghost: no row
+                const double4 pi = load_scalar4(a.pos, i);
+                double xi = pi.x, yi = pi.y, zi = pi.z;
+                if (!MI)
+                    {
+                    if (a.box.px) xi = __builtin_fma(-a.box.Lx, rint((xi - ccx) * a.box.Lxinv), xi);
+                    if (a.box.py) yi = __builtin_fma(-a.box.Ly, rint((yi - ccy) * a.box.Lyinv), yi);
+                    if (a.box.pz) zi = __builtin_fma(-a.box.Lz, rint((zi - ccz) * a.box.Lzinv), zi);
+                    }
+                const uint32_t typei = (uint32_t)type_from_w(pi.w);
+                const uint32_t nex = a.n_excl ? a.n_excl[i] : 0u;
+                uint32_t count = run[h];
+                uint32_t* out = FILL ? a.nlist + a.head_list[i] : nullptr;
+                for (uint32_t k = 0; k < nb_pad; k += 128)
+                    {
+                    bool accept[2];
+                    uint32_t jj[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        {
+                        const uint32_t c = k + 64u * u + lane;
+                        const uint32_t j = sidx[c];
+                        double dx = xi - sx[c], dy = yi - sy[c], dz = zi - sz[c];
+                        if (MI)
+                            min_image(a.box, dx, dy, dz);
+                        const double rsq = dx * dx + dy * dy + dz * dz;
+                        const double rl = one_type ? rl_single : a.rlistsq[typei * a.ntypes + styp[c]];
+                        bool acc = (j != i) && (j != NL_PAD_IDX) && (rl > 0.0) && (rsq <= rl);
+                        for (uint32_t e = 0; e < nex; ++e)
+                            acc &= (a.excl[(uint64_t)e * a.excl_pitch + i] != j);
+                        accept[u] = acc;
+                        jj[u] = j;
+                        }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        {
+                        const uint64_t mask = __ballot(accept[u]);
+                        if (FILL && accept[u])
+                            {
+                            const uint32_t below = __builtin_amdgcn_mbcnt_hi(
+                                (uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                            if (!a.row_capacity || count + below < a.row_capacity)
+                                out[count + below] = jj[u];
+                            }
+                        count += (uint32_t)__popcll(mask);
+                        }
+                    }
+                if (lane == 0)
+                    run[h] = count;
+                }
+            }
+        if (!FILL || a.row_capacity)
+            {
+            __syncthreads();
+            uint32_t most = 0;
+            for (uint32_t t = tid; t < nh; t += NL_THREADS)
+                {
+                const uint32_t i = a.order[hs + hc + t];
+                if (i < a.N)
+                    {
+                    a.n_neigh[i] = run[t];
+                    most = max(most, run[t]);
+                    }
+                }
+            if (FILL && most > a.row_capacity)
+                atomicMax(a.max_neigh, most); // overflow is rare: no reduction needed
+            }
+        __syncthreads();
+        }
     }
 
 static int check_nlist_args(const azp_nlist_args* a)
@@ -177,6 +326,8 @@ static NlistKArgs make_nlist_kargs(const azp_nlist_args& a)
     k.n_neigh = a.d_n_neigh;
     k.head_list = a.d_head_list;
     k.nlist = a.d_nlist;
+    k.max_neigh = a.d_max_neigh;
+    k.row_capacity = a.row_capacity;
     k.box = make_box_dev(a.box);
     k.grid = make_grid_dev(a.grid);
     k.N = a.N;
@@ -217,14 +368,30 @@ static int nlist_scan(const azp_nlist_args* args, void* stream, bool fill)
         return AZP_ERROR_INVALID_ARGUMENT;
     if (fill ? (!args->d_head_list || !args->d_nlist) : !args->d_n_neigh)
         return AZP_ERROR_INVALID_ARGUMENT;
+    if (fill && args->row_capacity && (!args->d_n_neigh || !args->d_max_neigh))
+        return AZP_ERROR_INVALID_ARGUMENT;
     if (args->N == 0)
         return AZP_SUCCESS;
     const NlistKArgs k = make_nlist_kargs(*args);
-    const uint32_t grid = (args->N + 255u) / 256u;
+    const uint32_t ncell = args->grid.dim[0] * args->grid.dim[1] * args->grid.dim[2];
+    const uint32_t grid = (ncell + 7u) & ~7u;
+    // images can be resolved once per staged candidate when every periodic axis
+    // has >= 4 cells (cell width + r_list <= L/2 with margin) and the box is orthorhombic
+    bool mi = k.box.triclinic;
+    for (int d = 0; d < 3; ++d)
+        if (args->grid.periodic[d] && args->grid.dim[d] < 4)
+            mi = true;
+    const hipStream_t s = static_cast<hipStream_t>(stream);
     if (fill)
-        hipLaunchKernelGGL(nlist_scan_kernel<true>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), k);
+        {
+        if (mi) hipLaunchKernelGGL((nlist_cell_kernel<true, true>), dim3(grid), dim3(NL_THREADS), 0, s, k, ncell, grid);
+        else hipLaunchKernelGGL((nlist_cell_kernel<true, false>), dim3(grid), dim3(NL_THREADS), 0, s, k, ncell, grid);
+        }
     else
-        hipLaunchKernelGGL(nlist_scan_kernel<false>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), k);
+        {
+        if (mi) hipLaunchKernelGGL((nlist_cell_kernel<false, true>), dim3(grid), dim3(NL_THREADS), 0, s, k, ncell, grid);
+        else hipLaunchKernelGGL((nlist_cell_kernel<false, false>), dim3(grid), dim3(NL_THREADS), 0, s, k, ncell, grid);
+        }
     return (int)hipGetLastError();
     }
 

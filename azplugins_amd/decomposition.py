@@ -271,7 +271,7 @@ def bench_main(args, rank, world, local_rank):
     sim.operations.integrator = azp.Integrator(dt=0.005, forces=[pot])
     halo.exchange(state.pos)
     sim.run(0)
-    mean_neigh = nl.size / max(dom.N_local, 1)
+    mean_neigh = nl.n_pairs / max(dom.N_local, 1)
 
     main = torch.cuda.current_stream()
     comm = torch.cuda.Stream()

@@ -26,6 +26,10 @@ class NeighborList:
         self.size = 0
         self._built_generation = None
         self.num_builds = 0
+        self.n_pairs = 0          # listed pairs = sum(n_neigh)
+        self.max_neigh = 0
+        self._row_capacity = 0    # > 0: rows of fixed capacity (single-pass rebuilds)
+        self.single_pass = True
 
     # -- consumers (pair potentials) register their r_cut matrices ---------
     def _add_consumer(self, force):
@@ -47,9 +51,15 @@ class NeighborList:
 class Cell(NeighborList):
     """Cell-list neighbor list (full storage, as HOOMD's GPU pair kernels use)."""
 
-    def compute(self, state, force=False):
+    def compute(self, state, force=False, compact=False):
         """Rebuild only when needed (HOOMD's criterion): never built, forced, or some
-        particle moved farther than buffer / 2 since the last build."""
+        particle moved farther than buffer / 2 since the last build.
+
+        The first build counts, scans and fills (exact rows). Later builds reuse the
+        row capacity learned from the previous one and run the fill alone (HOOMD's
+        protocol: fixed-capacity rows, rebuilt when a row overflows);
+        ``compact=True`` forces exact rows."""
+        self._compact = compact
         if not force and self.nlist is not None:
             if self._built_generation == state.position_generation:
                 return
@@ -129,14 +139,35 @@ class Cell(NeighborList):
 
         n_neigh = torch.empty(N, dtype=torch.int32, device=dev)
         a.d_n_neigh = n_neigh.data_ptr()
-        _lib.check(l.azp_nlist_count(C.byref(a), stream), "azp_nlist_count")
-        incl = torch.cumsum(n_neigh.to(torch.int64), 0)
-        head = incl - n_neigh.to(torch.int64)
-        size = int(incl[-1].item()) if N else 0
-        nlist = torch.empty(max(size, 1), dtype=torch.int32, device=dev)
-        a.d_head_list = head.data_ptr()
-        a.d_nlist = nlist.data_ptr()
-        _lib.check(l.azp_nlist_fill(C.byref(a), stream), "azp_nlist_fill")
+        done = False
+        cap = self._row_capacity
+        if self.single_pass and cap > 0 and N and not getattr(self, "_compact", False):
+            head = torch.arange(N, dtype=torch.int64, device=dev) * cap
+            size = N * cap
+            nlist = torch.empty(size, dtype=torch.int32, device=dev)
+            flag = torch.zeros(1, dtype=torch.int32, device=dev)
+            a.d_head_list = head.data_ptr()
+            a.d_nlist = nlist.data_ptr()
+            a.row_capacity = cap
+            a.d_max_neigh = flag.data_ptr()
+            _lib.check(l.azp_nlist_fill(C.byref(a), stream), "azp_nlist_fill")
+            stats = torch.stack([n_neigh.max().to(torch.int64), n_neigh.sum(dtype=torch.int64)]).tolist()
+            done = stats[0] <= cap  # else: a row overflowed, fall back to exact rows
+        if not done:
+            a.row_capacity = 0
+            a.d_max_neigh = None
+            _lib.check(l.azp_nlist_count(C.byref(a), stream), "azp_nlist_count")
+            incl = torch.cumsum(n_neigh.to(torch.int64), 0)
+            head = incl - n_neigh.to(torch.int64)
+            stats = torch.stack([n_neigh.max().to(torch.int64), incl[-1]]).tolist() if N else [0, 0]
+            size = int(stats[1])
+            nlist = torch.empty(max(size, 1), dtype=torch.int32, device=dev)
+            a.d_head_list = head.data_ptr()
+            a.d_nlist = nlist.data_ptr()
+            _lib.check(l.azp_nlist_fill(C.byref(a), stream), "azp_nlist_fill")
+        self.max_neigh, self.n_pairs = int(stats[0]), int(stats[1])
+        # next build: rows with ~6 % head room, multiple of 8 entries (32-B aligned rows)
+        self._row_capacity = (int(self.max_neigh * 1.06) + 4 + 7) // 8 * 8
 
         self.n_neigh, self.head_list, self.nlist, self.size = n_neigh, head, nlist, size
         self._pos_at_build = state.pos[:n_total, :3].clone()

@@ -177,7 +177,7 @@ def main():
         nl.num_builds += 1  # forces a plan rebuild
         del row, key
         pot.compute(0)
-    mean_neigh = nl.size / N
+    mean_neigh = nl.n_pairs / N
     if args.displace > 0.0:
         displace_particles(sim.state, args.displace * 0.5 * cfg["r_buff"], seed=11)
         pot.compute(0)

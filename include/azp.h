@@ -295,6 +295,16 @@ typedef struct azp_nlist_args
     uint32_t* d_n_neigh;        /* N, written by count                        */
     const uint64_t* d_head_list; /* N, read by fill                           */
     uint32_t* d_nlist;          /* written by fill                            */
+    /* single-pass mode of azp_nlist_fill (HOOMD's own protocol: rows of fixed
+     * capacity, rebuilt with larger rows on overflow): when row_capacity > 0 the
+     * fill also writes d_n_neigh[i] (the full count), stores at most row_capacity
+     * entries per row and raises *d_max_neigh to the largest count seen
+     * (atomic max; the caller zeroes it before the launch and must rebuild with
+     * larger rows if it exceeds row_capacity). row_capacity = 0: rows are exact
+     * (head_list from a scan of the count pass). */
+    uint32_t row_capacity;
+    uint32_t _pad2;
+    uint32_t* d_max_neigh;
     } azp_nlist_args;
 
 int azp_nlist_cell_assign(const azp_nlist_args* args, void* stream);

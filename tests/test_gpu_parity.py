@@ -603,6 +603,49 @@ def test_product_nlist_matches_oracle(oracle):
     assert_close(np.c_[pot.forces, pot.energies], f_ref)
 
 
+def test_nlist_single_pass_rebuild_and_overflow(oracle):
+    """Rebuilds use fixed-capacity rows and the fill alone; the listed pairs and the
+    forces are the same as with exact rows, and a row overflow falls back to exact rows."""
+    import azplugins_amd as azp
+
+    cfg = syn.config_plj_sc(14)
+    n = cfg["xyz"].shape[0]
+    sim = azp.Simulation(device="cuda:0", seed=1)
+    sim.create_state_from_snapshot(azp.Snapshot.from_arrays(cfg["xyz"], cfg["L"]))
+    nl = azp.nlist.Cell(buffer=0.4)
+    pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=2.0)
+    pot.params[("A", "A")] = cfg["params"]
+    sim.operations.integrator = azp.Integrator(dt=0.001, forces=[pot])
+    sim.run(0)
+
+    def rows():
+        nn = nl.n_neigh.cpu().numpy().astype(np.int64)
+        hd = nl.head_list.cpu().numpy()
+        li = nl.nlist.cpu().numpy()
+        return nn, [np.sort(li[hd[i]: hd[i] + nn[i]]) for i in range(n)]
+
+    nn0, rows0 = rows()
+    f0 = np.c_[pot.forces, pot.energies]
+    assert nl.n_pairs == nn0.sum() and nl.max_neigh == nn0.max()
+    pos = syn.pos4(cfg["xyz"])
+    o_n, o_head, o_list = oracle.build_nlist(pos, oracle.make_box(cfg["L"]), 2.4)
+    assert np.array_equal(nn0, o_n)
+    cap = nl._row_capacity
+    assert cap >= nn0.max() and cap % 8 == 0
+    nl.compute(sim.state, force=True)          # single pass, strided rows
+    assert int(nl.head_list[1].item()) == cap and nl.size == n * cap
+    nn1, rows1 = rows()
+    assert np.array_equal(nn0, nn1) and all(np.array_equal(a, b) for a, b in zip(rows0, rows1))
+    pot.compute(0)
+    assert_close(np.c_[pot.forces, pot.energies], f0)
+    nl._row_capacity = 8                         # guaranteed overflow -> exact rows again
+    nl.compute(sim.state, force=True)
+    nn2, rows2 = rows()
+    assert nl.size == nn0.sum()
+    assert np.array_equal(nn0, nn2) and all(np.array_equal(a, b) for a, b in zip(rows0, rows2))
+    assert nl._row_capacity == cap
+
+
 def test_api_virial_and_modes_multitype(oracle):
     """hoomd.azplugins-shaped API: 3 types, xplor mode, virials, PerturbedLJ."""
     import azplugins_amd as azp

@@ -35,7 +35,8 @@ def test_abi_struct_sizes_match_header():
 
     names = ["azp_box", "azp_pair_args", "azp_dpd_args", "azp_aniso_args", "azp_bond_args", "azp_cell_grid",
              "azp_nlist_args", "azp_plj_params", "azp_hertz_params", "azp_yukawa_params", "azp_colloid_params",
-             "azp_dpd_params", "azp_tpm_params", "azp_dw_params", "azp_quartic_params", "azp_bond_entry"]
+             "azp_dpd_params", "azp_tpm_params", "azp_dw_params", "azp_quartic_params", "azp_bond_entry",
+             "azp_barrier_args", "azp_nve_args"]
     src = '#include <stdio.h>\n#include "azp.h"\nint main(){' + "".join(
         'printf("%%zu\\n", sizeof(%s));' % n for n in names) + "return 0;}"
     with tempfile.TemporaryDirectory() as d:
@@ -54,6 +55,8 @@ def test_abi_struct_sizes_match_header():
     # parameter structs are byte-compatible with the reference's param_type
     assert [got[n] for n in names[7:15]] == [32, 8, 32, 32, 32, 48, 32, 64]
     assert got["azp_bond_entry"] == 8
+    assert got["azp_barrier_args"] == C.sizeof(_lib.BarrierArgs)
+    assert got["azp_nve_args"] == C.sizeof(_lib.NVEArgs)
 
 
 def test_oracle_struct_sizes(oracle):

@@ -69,7 +69,7 @@ def run(name, cfg, quick):
     sim.operations.integrator = azp.Integrator(dt=cfg.get("dt", 0.005), forces=forces)
     sim.timestep = 12345
     sim.run(0)
-    mean_n = nl.size / N
+    mean_n = nl.n_pairs / N
     rows = []
     # ---- parity on the same snapshot and the same list
     pos = syn.pos4(cfg["xyz"])
