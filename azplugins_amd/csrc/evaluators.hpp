@@ -90,6 +90,33 @@ struct EvalPLJ
         pair_eng = __builtin_fma(e, scale, __builtin_fma(m, c.wca_minus_tail, tail));
         return in;
         }
+    // Tile kernel, single type pair, no xplor: the two energy offsets (WCA shift in
+    // the core, -e_cut inside the cutoff) are the same constants for every pair, so
+    // the pairs are only COUNTED here (one add-with-carry each) and the offsets are
+    // applied once per particle in finish_split -- 4 FP64-rate ops fewer per pair
+    // than eval (no blended offset, no 64-bit select, one Newton step less).
+    static constexpr bool kSplitEnergy = true;
+    static __device__ __forceinline__ void eval_split(const Coeff& c, double rsq, double& force_divr, double& pe_raw,
+                                                      uint32_t& n_wca, uint32_t& n_in)
+        {
+        const bool in = rsq < c.rcutsq;
+        const bool wca = rsq < c.wca_rsq;
+        const double x = fast_rcp1(rsq);
+        const double r2inv = __hiloint2double(in ? __double2hiint(x) : 0, __double2loint(x));
+        const double m = __hiloint2double(wca ? 0x3ff00000 : 0, 0);
+        const double r6inv = r2inv * r2inv * r2inv;
+        const double f = r2inv * r6inv * __builtin_fma(c.c12, r6inv, -c.c6);
+        const double e = r6inv * __builtin_fma(c.lj1, r6inv, -c.lj2);
+        const double scale = __builtin_fma(m, c.one_minus_lam, c.lam);
+        force_divr = f * scale;
+        pe_raw = __builtin_fma(e, scale, pe_raw);
+        n_wca += wca ? 1u : 0u;
+        n_in += in ? 1u : 0u;
+        }
+    static __device__ __forceinline__ double finish_split(const Coeff& c, double pe_raw, uint32_t n_wca, uint32_t n_in)
+        {
+        return __builtin_fma((double)n_wca, c.wca_minus_tail, __builtin_fma((double)n_in, c.tail_add, pe_raw));
+        }
     };
 
 // ---------------------------------------------------------------------------
@@ -98,6 +125,7 @@ struct EvalPLJ
 struct EvalHertz
     {
     typedef azp_hertz_params Params;
+    static constexpr bool kSplitEnergy = false;
     struct Coeff
         {
         double rcutsq, epsilon, rcut, rcutinv;
@@ -135,6 +163,7 @@ struct EvalHertz
 struct EvalYukawa
     {
     typedef azp_yukawa_params Params;
+    static constexpr bool kSplitEnergy = false;
     struct Coeff
         {
         double rcutsq, epsilon, kappa, delta, e_cut;
@@ -180,6 +209,7 @@ struct EvalYukawa
 struct EvalColloid
     {
     typedef azp_colloid_params Params;
+    static constexpr bool kSplitEnergy = false;
     struct Coeff
         {
         double rcutsq, A, ai, aj, sigma_3, sigma_6, e_cut;
@@ -313,6 +343,7 @@ struct EvalColloid
 struct EvalDPDConservative
     {
     typedef azp_dpd_params Params;
+    static constexpr bool kSplitEnergy = false;
     struct Coeff
         {
         double rcutsq, A, gamma, half_s, rcut, rcutinv;
@@ -407,6 +438,7 @@ __device__ __forceinline__ double dpd_alpha(uint16_t seed, uint32_t tag_i, uint3
 struct EvalDoubleWell // src/BondEvaluatorDoubleWell.h:96-113
     {
     typedef azp_dw_params Params;
+    static constexpr bool kSplitEnergy = false;
     static __device__ __forceinline__ bool eval(const Params& p, double rsq, double& force_divr, double& bond_eng)
         {
         bond_eng = 0.0;
@@ -427,6 +459,7 @@ struct EvalDoubleWell // src/BondEvaluatorDoubleWell.h:96-113
 struct EvalQuartic // src/BondEvaluatorQuartic.h:113-200
     {
     typedef azp_quartic_params Params;
+    static constexpr bool kSplitEnergy = false;
     static __device__ __forceinline__ bool eval(const Params& p, double rsq, double& force_divr, double& bond_eng)
         {
         const double lj1 = p.epsilon_x_4 * p.sigma_6 * p.sigma_6;

@@ -87,10 +87,11 @@ __device__ __forceinline__ void tile_compute(const TileBatch& b, const TiledKArg
                                              const typename E::Coeff* __restrict__ s_coeff,
                                              const double* __restrict__ s_ronsq, const typename E::Coeff& c0, double ronsq0,
                                              double rcutsq_max, const double3& pi, int typei, double& fx, double& fy,
-                                             double& fz, double& pe, double (&v)[6])
+                                             double& fz, double& pe, double (&v)[6], uint32_t& n_core, uint32_t& n_in)
     {
     typedef typename E::Coeff Coeff;
     constexpr int NB = AZP_TILE_BATCH;
+    constexpr bool SPLIT = SINGLE && !XPLOR && E::kSplitEnergy; // energy offsets counted, see EvalPLJ::eval_split
     double dx[NB], dy[NB], dz[NB], rsq[NB];
     bool any_in = false;
 #pragma unroll
@@ -113,8 +114,10 @@ __device__ __forceinline__ void tile_compute(const TileBatch& b, const TiledKArg
 #pragma unroll
     for (int e = 0; e < NB; ++e)
         {
-        double force_divr, pair_eng;
-        if (SINGLE)
+        double force_divr, pair_eng = 0.0;
+        if constexpr (SPLIT)
+            E::eval_split(c0, rsq[e], force_divr, pe, n_core, n_in);
+        else if (SINGLE)
             {
             const bool evaluated = E::eval(c0, rsq[e], force_divr, pair_eng);
             if (XPLOR && evaluated)
@@ -132,7 +135,8 @@ __device__ __forceinline__ void tile_compute(const TileBatch& b, const TiledKArg
         fx = __builtin_fma(dx[e], force_divr, fx);
         fy = __builtin_fma(dy[e], force_divr, fy);
         fz = __builtin_fma(dz[e], force_divr, fz);
-        pe += pair_eng;
+        if constexpr (!SPLIT)
+            pe += pair_eng;
         if (VIRIAL)
             {
             const double fxx = force_divr * dx[e], fyy = force_divr * dy[e];
@@ -156,45 +160,57 @@ template<class E, int TPP, int CAP, bool VIRIAL, bool SINGLE, bool XPLOR, bool W
 __device__ __forceinline__ void tiled_loop(const TiledKArgs& a, const char* bx, const char* bt,
                                            const typename E::Coeff* __restrict__ s_coeff,
                                            const double* __restrict__ s_ronsq, const typename E::Coeff& c0, double ronsq0,
-                                           double rcutsq_max, const uint4* __restrict__ chunks, uint32_t K, double3 pi,
-                                           int typei, double& fx, double& fy, double& fz, double& pe, double (&v)[6])
+                                           double rcutsq_max, const char* __restrict__ slice_base, uint32_t lane_off, uint32_t K, double3 pi,
+                                           int typei, double& fx, double& fy, double& fz, double& pe, double (&v)[6], uint32_t& n_core,
+                                           uint32_t& n_in)
     {
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    // chunk kk of this lane: uniform base + kk KiB (scalar) + 16 lane (one VGPR)
+    auto chunk_at = [&](uint32_t kk) -> uint4
+        { return *reinterpret_cast<const uint4*>(slice_base + (uint64_t)kk * 1024u + lane_off); };
 #if AZP_TILE_BATCH == 4
-    uint4 u = (K > 0) ? chunks[0] : zero4;
+    // (prefetching the chunk indices two iterations ahead instead of one costs 9 more
+    // spilled registers and measures 3 % slower)
+    uint4 u = (K > 0) ? chunk_at(0) : zero4;
+    uint4 un = (K > 1) ? chunk_at(1) : u;
     TileBatch A, B;
     tile_gather<CAP, 0>(A, u, bx);
     for (uint32_t kk = 0; kk < K; ++kk)
         {
-        const uint4 un = (kk + 1 < K) ? chunks[(uint64_t)(kk + 1) * 64] : zero4; // next chunk's indices
+        // indices two chunks ahead (consumed 1.5 iterations from now: one iteration
+        // does not always cover an HBM round trip); past the end the last chunk is
+        // reloaded (an unconditional 16-byte load: a predicated one is split into
+        // four 4-byte loads)
+        const uint4 un2 = chunk_at((kk + 2 < K) ? kk + 2 : K - 1);
         tile_gather<CAP, 1>(B, u, bx);
         __builtin_amdgcn_sched_barrier(0);
-        tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(A, a, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, pi, typei, fx, fy, fz, pe, v);
+        tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(A, a, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, pi, typei, fx, fy, fz, pe, v, n_core, n_in);
         __builtin_amdgcn_sched_barrier(0);
-        tile_gather<CAP, 0>(A, un, bx); // padding slot when kk + 1 == K: gathered, never used
+        tile_gather<CAP, 0>(A, un, bx); // when kk + 1 == K: gathered, never used
         __builtin_amdgcn_sched_barrier(0);
-        tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(B, a, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, pi, typei, fx, fy, fz, pe, v);
+        tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(B, a, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, pi, typei, fx, fy, fz, pe, v, n_core, n_in);
         __builtin_amdgcn_sched_barrier(0);
         u = un;
+        un = un2;
         }
 #else
     // whole-chunk batches: chunk k+1's 24 gathers fly while chunk k is evaluated
-    uint4 u0 = (K > 0) ? chunks[0] : zero4;
-    uint4 u1 = (K > 1) ? chunks[64] : zero4;
+    uint4 u0 = (K > 0) ? chunk_at(0) : zero4;
+    uint4 u1 = (K > 1) ? chunk_at(1) : zero4;
     TileBatch A, B;
     tile_gather<CAP, 0>(A, u0, bx);
     for (uint32_t kk = 0; kk < K; kk += 2)
         {
-        const uint4 u2 = (kk + 2 < K) ? chunks[(uint64_t)(kk + 2) * 64] : zero4;
-        const uint4 u3 = (kk + 3 < K) ? chunks[(uint64_t)(kk + 3) * 64] : zero4;
+        const uint4 u2 = (kk + 2 < K) ? chunk_at(kk + 2) : zero4;
+        const uint4 u3 = (kk + 3 < K) ? chunk_at(kk + 3) : zero4;
         tile_gather<CAP, 0>(B, u1, bx);
         __builtin_amdgcn_sched_barrier(0);
-        tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(A, a, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, pi, typei, fx, fy, fz, pe, v);
+        tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(A, a, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, pi, typei, fx, fy, fz, pe, v, n_core, n_in);
         __builtin_amdgcn_sched_barrier(0);
         tile_gather<CAP, 0>(A, u2, bx);
         __builtin_amdgcn_sched_barrier(0);
         if (kk + 1 < K)
-            tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(B, a, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, pi, typei, fx, fy, fz, pe, v);
+            tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(B, a, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, pi, typei, fx, fy, fz, pe, v, n_core, n_in);
         __builtin_amdgcn_sched_barrier(0);
         u1 = u3;
         }
@@ -227,10 +243,10 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
     double rcutsq_max = 0.0; // largest cutoff^2 over the type pairs: bound for the skip test
     if (SINGLE)
         {
-        c0 = prepare_coeff<E>(a.p, params, 0);
+        c0 = to_uniform(prepare_coeff<E>(a.p, params, 0)); // same for every lane: keep it in SGPRs
         if (XPLOR)
             ronsq0 = a.p.ronsq[0];
-        rcutsq_max = a.p.rcutsq[0];
+        rcutsq_max = c0.rcutsq; // the evaluator's own (effective) cutoff: one compare serves both tests
         }
     else
         {
@@ -283,7 +299,7 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
         }
 
     // ---- this lane's particle, in the same image frame ----
-    const uint32_t wave = tid >> 6, lane = tid & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63; // wave id: scalar
     const uint32_t pl = lane / TPP;
     const uint32_t idx = first + wave * PW + pl;
     const bool active = idx < a.p.end;
@@ -312,19 +328,25 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
     const bool wide = __syncthreads_or(lane_wide); // also publishes the staged tile
 
     const uint32_t slice = tile * 4 + wave;
-    const uint32_t K = a.slice_K[slice];
-    const uint4* __restrict__ chunks = a.cnl + a.slice_head[slice] * 64ull + lane;
+    const uint32_t K = to_uniform(a.slice_K[slice]); // scalar trip count: the loop counter and the chunk address stay in SGPRs
+    // wave-uniform slice base (SGPRs) + lane: the loads use scalar-base addressing
+    const uint64_t slice_head = to_uniform(a.slice_head[slice]);
+    const char* __restrict__ slice_base = reinterpret_cast<const char*>(a.cnl + slice_head * 64ull);
+    const uint32_t lane_off = lane * 16u;
 
     double fx = 0.0, fy = 0.0, fz = 0.0, pe = 0.0;
     double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    uint32_t n_core = 0, n_in = 0;
     const char* bx = reinterpret_cast<const char*>(s_x);
     const char* bt = reinterpret_cast<const char*>(s_t);
     if (wide)
-        tiled_loop<E, TPP, CAP, VIRIAL, SINGLE, XPLOR, true>(a, bx, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, chunks, K, pi,
-                                                            typei, fx, fy, fz, pe, v);
+        tiled_loop<E, TPP, CAP, VIRIAL, SINGLE, XPLOR, true>(a, bx, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, slice_base, lane_off, K, pi,
+                                                            typei, fx, fy, fz, pe, v, n_core, n_in);
     else
-        tiled_loop<E, TPP, CAP, VIRIAL, SINGLE, XPLOR, false>(a, bx, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, chunks, K, pi,
-                                                             typei, fx, fy, fz, pe, v);
+        tiled_loop<E, TPP, CAP, VIRIAL, SINGLE, XPLOR, false>(a, bx, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, slice_base, lane_off, K, pi,
+                                                             typei, fx, fy, fz, pe, v, n_core, n_in);
+    if constexpr (SINGLE && !XPLOR && E::kSplitEnergy)
+        pe = E::finish_split(c0, pe, n_core, n_in);
 
     fx = group_sum<TPP>(fx);
     fy = group_sum<TPP>(fy);

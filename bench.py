@@ -41,6 +41,8 @@ def make_workload(name):
         return syn.config_north_star(16)
     if name == "c2":
         return syn.config_plj_sc(64)
+    if name.startswith("ns-x"):  # ns-x2 / ns-x4 / ns-x8: the north star repeated along z (scaling studies)
+        return syn.config_north_star((64, 64, 64 * int(name[4:])))
     raise SystemExit("unknown workload %r" % name)
 
 
