@@ -47,6 +47,7 @@ class PairArgs(C.Structure):
         ("range_first", C.c_uint32),
         ("range_count", C.c_uint32),
         ("r_list_max", C.c_double),
+        ("d_rinnersq", C.c_void_p),
     ]
 
 

@@ -34,6 +34,7 @@ struct EvalPLJ
         double wca_rsq;   // min(rwcasq, effective rcutsq): inside => WCA core AND inside the cutoff
         double wca_minus_tail; // (wca_shift - e_cut) - (-e_cut) = wca_shift
         double tail_add;  // -e_cut                 (energy offset in the scaled tail)
+        double c12_lam, c6_lam; // lam c12, lam c6: the tail's force coefficients
         };
     static __device__ __forceinline__ Coeff prepare(const Params& p, double rcutsq, bool energy_shift)
         {
@@ -63,6 +64,8 @@ struct EvalPLJ
         c.wca_rsq = (p.rwcasq < c.rcutsq) ? p.rwcasq : c.rcutsq;
         c.tail_add = -e_cut;
         c.wca_minus_tail = (wca_shift - e_cut) - c.tail_add;
+        c.c12_lam = lam * c.c12;
+        c.c6_lam = lam * c.c6;
         return c;
         }
     static __device__ __forceinline__ bool eval(const Coeff& c, double rsq, double& force_divr, double& pair_eng)
@@ -111,6 +114,21 @@ struct EvalPLJ
         force_divr = f * scale;
         pe_raw = __builtin_fma(e, scale, pe_raw);
         n_wca += wca ? 1u : 0u;
+        n_in += in ? 1u : 0u;
+        }
+    // true when the pair needs eval_split's core/tail blend; eval_split_tail is valid
+    // for every pair of a batch in which no lane saw a core pair (wave-uniform test)
+    static __device__ __forceinline__ bool in_core(const Coeff& c, double rsq) { return rsq < c.wca_rsq; }
+    static __device__ __forceinline__ void eval_split_tail(const Coeff& c, double rsq, double& force_divr, double& pe_raw,
+                                                           uint32_t& n_in)
+        {
+        const bool in = rsq < c.rcutsq;
+        const double x = fast_rcp1(rsq);
+        const double r2inv = __hiloint2double(in ? __double2hiint(x) : 0, __double2loint(x));
+        const double r6inv = r2inv * r2inv * r2inv;
+        force_divr = r2inv * r6inv * __builtin_fma(c.c12_lam, r6inv, -c.c6_lam);
+        const double e = r6inv * __builtin_fma(c.lj1, r6inv, -c.lj2);
+        pe_raw = __builtin_fma(e, c.lam, pe_raw);
         n_in += in ? 1u : 0u;
         }
     static __device__ __forceinline__ double finish_split(const Coeff& c, double pe_raw, uint32_t n_wca, uint32_t n_in)

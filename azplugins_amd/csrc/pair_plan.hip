@@ -28,6 +28,7 @@ struct PlanKArgs
     const uint32_t* nlist;
     const uint64_t* head_list;
     const double* rcutsq;
+    const double* rinnersq; // optional (may be null): "core" class radius^2 per type pair
     uint32_t* tile_nstage;
     uint64_t* tile_head;
     uint32_t* stage_idx;
@@ -128,7 +129,7 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
     __shared__ double s_rcutsq[64]; // up to 8 types cached; more types read the global table
     // bank-aware row ordering (TPP == 1): per wave 32 (part, bank) counters, 2 misfit
     // counters and the list of unclaimed positions
-    __shared__ uint32_t s_bank_cnt[PLAN_BUILD_WAVES][34];
+    __shared__ uint32_t s_bank_cnt[PLAN_BUILD_WAVES][52];
     __shared__ uint16_t s_holes[PLAN_BUILD_WAVES][PLAN_ROWBUF];
 
     const uint32_t tid = threadIdx.x;
@@ -303,16 +304,18 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
             jj[it] = (k < n) ? row[k] : PLAN_EMPTY;
             }
         const uint32_t iters = (n + 63u) >> 6;
-        // pass A: translate + classify, count the near entries
-        uint32_t n_near = 0;
-        uint32_t enc[ITERS]; // (offset << 1) | near, 0 = no entry
+        // pass A: translate + classify. Classes: 0 core (inside the evaluator's inner
+        // radius hint, e.g. the WCA core of PerturbedLJ), 1 near (inside the cutoff
+        // now), 2 far (only in the Verlet buffer). Rows are written core | near | far.
+        uint32_t n_core = 0, n_near = 0;
+        uint32_t enc[ITERS]; // (offset << 2) | class, 0 = no entry
 #pragma unroll
         for (int it = 0; it < ITERS; ++it)
             {
             enc[it] = 0;
             if ((uint32_t)it < iters)
                 {
-                bool near = false;
+                bool near = false, core = false;
                 if (jj[it] != PLAN_EMPTY)
                     {
                     const uint32_t sidx = slot_of[plan_find<HC>(table, jj[it])];
@@ -321,12 +324,16 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
                     min_image(a.box, dx, dy, dz);
                     const double rsq = dx * dx + dy * dy + dz * dz;
                     const uint32_t tp = trow + (uint32_t)__float_as_int(q.w);
-                    near = rsq < (rc_cached ? s_rcutsq[tp] : a.rcutsq[tp]);
-                    enc[it] = (((sidx + 1u) * 8u) << 1) | (near ? 1u : 0u);
+                    const bool in = rsq < (rc_cached ? s_rcutsq[tp] : a.rcutsq[tp]);
+                    core = in && a.rinnersq && rsq < a.rinnersq[tp];
+                    near = in && !core;
+                    enc[it] = (((sidx + 1u) * 8u) << 2) | (core ? 0u : (near ? 1u : 2u));
                     }
+                n_core += (uint32_t)__popcll(__ballot(core));
                 n_near += (uint32_t)__popcll(__ballot(near));
                 }
             }
+        const uint32_t seg[4] = {0u, n_core, n_core + n_near, n};
         if (TPP == 1 && PLAN_BANK_ORDER)
             {
             // pass B (bank-aware): lane l of the force kernel reads its row entry q at
@@ -335,13 +342,13 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
             // conflict-free when the 16 lanes of a group touch 16 different 8-byte
             // bank pairs (slot mod 16), or the same slot. Give position q of row l
             // the "home" bank (l + q) mod 16: within a group all homes differ. An
-            // entry goes to the next free home position of its bank inside its part
-            // (near / far); the ~16 % that do not fit (banks are not evenly used by
-            // one row) fill the positions left over. Measured on the gather pattern
-            // alone (tools/lds_bench.hip): 10.7 -> 7.4 LDS cycles per wave read.
+            // entry goes to the next free home position of its bank inside its class;
+            // the ~16 % that do not fit (banks are not evenly used by one row) fill
+            // the positions left over. Measured on the gather pattern alone
+            // (tools/lds_bench.hip): 10.7 -> 7.4 LDS cycles per wave read.
             uint32_t* cnt = s_bank_cnt[wave];
             uint16_t* holes = s_holes[wave];
-            if (lane < 34)
+            if (lane < 52)
                 cnt[lane] = 0;
             for (uint32_t t = lane; t < row_cap; t += 64)
                 rowbuf[t] = (t < n) ? (uint16_t)0xffffu : (uint16_t)0; // unclaimed | padding
@@ -352,10 +359,10 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
                 {
                 if ((uint32_t)it < iters && enc[it] != 0)
                     {
-                    const bool near = enc[it] & 1u;
-                    const uint32_t off = enc[it] >> 1, bank = (off >> 3) & 15u;
-                    const uint32_t r = atomicAdd(&cnt[(near ? 0u : 16u) + bank], 1u);
-                    const uint32_t b = near ? 0u : n_near, e = near ? n_near : n;
+                    const uint32_t cls = enc[it] & 3u;
+                    const uint32_t off = enc[it] >> 2, bank = (off >> 3) & 15u;
+                    const uint32_t r = atomicAdd(&cnt[cls * 16u + bank], 1u);
+                    const uint32_t b = seg[cls], e = seg[cls + 1];
                     const uint32_t q = b + ((bank - pl - b) & 15u) + 16u * r;
                     if (q < e)
                         rowbuf[q] = (uint16_t)off;
@@ -364,8 +371,8 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
                     }
                 }
             __builtin_amdgcn_wave_barrier();
-            // unclaimed positions, in order (those of the near part first)
-            uint32_t n_holes = 0, holes_near = 0;
+            // unclaimed positions, in order (class by class)
+            uint32_t n_holes = 0, holes_c0 = 0, holes_c01 = 0;
             for (uint32_t t0 = 0; t0 < n; t0 += 64)
                 {
                 const uint32_t t = t0 + lane;
@@ -374,7 +381,8 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
                 if (hole)
                     holes[n_holes + (uint32_t)__popcll(m & lt_mask)] = (uint16_t)t;
                 n_holes += (uint32_t)__popcll(m);
-                holes_near += (uint32_t)__popcll(__ballot(hole && t < n_near));
+                holes_c0 += (uint32_t)__popcll(__ballot(hole && t < seg[1]));
+                holes_c01 += (uint32_t)__popcll(__ballot(hole && t < seg[2]));
                 }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -382,36 +390,37 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
                 {
                 if (misfit & (1u << it))
                     {
-                    const bool near = enc[it] & 1u;
-                    const uint32_t m = atomicAdd(&cnt[near ? 32 : 33], 1u) + (near ? 0u : holes_near);
-                    rowbuf[holes[m]] = (uint16_t)(enc[it] >> 1);
+                    const uint32_t cls = enc[it] & 3u;
+                    const uint32_t m = atomicAdd(&cnt[48u + cls], 1u) + (cls == 0 ? 0u : (cls == 1 ? holes_c0 : holes_c01));
+                    rowbuf[holes[m]] = (uint16_t)(enc[it] >> 2);
                     }
                 }
             __builtin_amdgcn_wave_barrier();
             }
         else
             {
-        // pass B: scatter into the row buffer, near part first
-        uint32_t base_near = 0, base_far = n_near;
+            // pass B: stable three-way partition into the row buffer
+            uint32_t base[3] = {seg[0], seg[1], seg[2]};
 #pragma unroll
-        for (int it = 0; it < ITERS; ++it)
-            {
-            if ((uint32_t)it < iters)
+            for (int it = 0; it < ITERS; ++it)
                 {
-                const bool valid = enc[it] != 0;
-                const bool near = enc[it] & 1u;
-                const uint64_t m_near = __ballot(valid && near);
-                const uint64_t m_far = __ballot(valid && !near);
-                if (valid)
+                if ((uint32_t)it < iters)
                     {
-                    const uint32_t posn = near ? base_near + (uint32_t)__popcll(m_near & lt_mask)
-                                               : base_far + (uint32_t)__popcll(m_far & lt_mask);
-                    rowbuf[posn] = (uint16_t)(enc[it] >> 1);
+                    const bool valid = enc[it] != 0;
+                    const uint32_t cls = enc[it] & 3u;
+                    uint32_t posn = 0;
+#pragma unroll
+                    for (uint32_t cidx = 0; cidx < 3; ++cidx)
+                        {
+                        const uint64_t m = __ballot(valid && cls == cidx);
+                        if (cls == cidx)
+                            posn = base[cidx] + (uint32_t)__popcll(m & lt_mask);
+                        base[cidx] += (uint32_t)__popcll(m);
+                        }
+                    if (valid)
+                        rowbuf[posn] = (uint16_t)(enc[it] >> 2);
                     }
-                base_near += (uint32_t)__popcll(m_near);
-                base_far += (uint32_t)__popcll(m_far);
                 }
-            }
             // pad to the slice's rectangle with the dummy slot
             for (uint32_t t = n + lane; t < row_cap; t += 64)
                 rowbuf[t] = 0;
@@ -534,6 +543,7 @@ static int plan_build_tpp(PairPlan& p, const azp_pair_args& args, uint32_t tpp, 
     k.nlist = args.d_nlist;
     k.head_list = args.d_head_list;
     k.rcutsq = args.d_rcutsq;
+    k.rinnersq = args.d_rinnersq;
     k.tile_nstage = p.d_tile_nstage;
     k.tile_head = p.d_tile_head;
     k.stage_idx = nullptr;

@@ -13,3 +13,11 @@ extern "C" int azp_pair_forces_planned_perturbed_lennard_jones(azp_pair_plan* pl
     {
     return azp::launch_pair_planned<azp::EvalPLJ>(plan, args, d_params, stream);
     }
+
+#ifdef AZP_TIMELINE
+namespace azp { __device__ unsigned long long g_timeline[8 * 4 * 16384]; }
+extern "C" int azp_debug_timeline(unsigned long long* out, size_t n_words)
+    {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(azp::g_timeline), n_words * sizeof(unsigned long long));
+    }
+#endif

@@ -24,6 +24,12 @@
 
 namespace azp
 {
+#ifdef AZP_TIMELINE
+// debug build only (tools/timeline.py): per (tile, wave) realtime stamps (100 MHz):
+// kernel entry, tile staged, loop done, and the hardware id of the wave
+extern __device__ unsigned long long g_timeline[8 * 4 * 16384];
+#endif
+
 struct TiledKArgs
     {
     PairKArgs p;
@@ -111,6 +117,29 @@ __device__ __forceinline__ void tile_compute(const TileBatch& b, const TiledKArg
 #endif
     if (!__any(any_in))
         return;
+    if constexpr (SPLIT && !VIRIAL)
+        {
+        // rows list the pairs inside the evaluator's core first (plan hint), so beyond
+        // the first chunks no lane of the wave has one and the cheaper tail-only form
+        // applies to the whole batch (exact: tested on the actual separations)
+        bool any_core = false;
+#pragma unroll
+        for (int e = 0; e < NB; ++e)
+            any_core = any_core || E::in_core(c0, rsq[e]);
+        if (!__any(any_core))
+            {
+#pragma unroll
+            for (int e = 0; e < NB; ++e)
+                {
+                double force_divr;
+                E::eval_split_tail(c0, rsq[e], force_divr, pe, n_in);
+                fx = __builtin_fma(dx[e], force_divr, fx);
+                fy = __builtin_fma(dy[e], force_divr, fy);
+                fz = __builtin_fma(dz[e], force_divr, fz);
+                }
+            return;
+            }
+        }
 #pragma unroll
     for (int e = 0; e < NB; ++e)
         {
@@ -232,6 +261,17 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
     double* s_ronsq = reinterpret_cast<double*>(s_coeff + (SINGLE ? 0 : a.p.ntypes * a.p.ntypes));
 
     const uint32_t tid = threadIdx.x;
+#ifndef AZP_NO_STAGE_PRIO
+    // A new tile's waves share their SIMDs with three older waves that are deep in
+    // the pair loop; raise the priority while staging so the short prologue is not
+    // starved (tools/timeline.py: the staging took 17 of a tile's 41 us).
+    __builtin_amdgcn_s_setprio(3);
+#endif
+#ifdef AZP_TIMELINE
+    const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long tl_c0 = __builtin_amdgcn_s_memtime(); // shader clock
+    unsigned long long tl_tb = 0, tl_tc = 0, tl_td = 0, tl_ta = 0;
+#endif
     // a.p.first / a.p.end are tile-aligned outwards by the launcher
     const uint32_t tile = a.p.first / TB + xcd_remap(blockIdx.x, a.p.nblocks_padded);
     const uint32_t first = tile * TB;
@@ -260,6 +300,9 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
             rcutsq_max = fmax(rcutsq_max, a.p.rcutsq[t]);
         }
 
+#ifdef AZP_TIMELINE
+    tl_ta = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- stage: positions shifted to the periodic image nearest the tile's
     // reference particle c ----
     const uint32_t n_stage = a.tile_nstage[tile];
@@ -270,33 +313,63 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
         s_x[0] = PLAN_FAR; s_y[0] = PLAN_FAR; s_z[0] = PLAN_FAR;
         if (!SINGLE) s_t[0] = 0;
         }
-#if defined(AZP_ABLATE) && (AZP_ABLATE == 1)
-    for (uint32_t s = tid; s < 0 * n_stage; s += 256) // ablation 1: no staging loads
-#else
-    for (uint32_t s = tid; s < n_stage; s += 256)
-#endif
+    // All loads of the staging are issued before the first result is used: the index
+    // loads of every round first, then every position load (two dependent HBM round
+    // trips per tile instead of two per 256 staged particles -- the staging took 17 of
+    // a tile's 41 us when it was written as a plain loop, tools/timeline.py).
+    {
+    constexpr int ROUNDS = CAP / 256; // CAP is a multiple of 256 and n_stage < CAP
+    uint32_t sj[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r)
         {
-        const uint32_t j = stage[s];
-        double x, y, z;
+        const uint32_t sidx = (uint32_t)r * 256u + tid;
+        sj[r] = (sidx < n_stage) ? stage[sidx] : first; // out-of-range lanes load the reference particle (unused)
+        }
+#ifdef AZP_TIMELINE
+    __builtin_amdgcn_s_waitcnt(0); // all counters
+    tl_tb = __builtin_amdgcn_s_memrealtime();
+#endif
+    double sxv[ROUNDS], syv[ROUNDS], szv[ROUNDS];
+    int stv[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r)
+        {
         if (SINGLE)
             {
-            const double3 pj = load_scalar3_of4(a.p.pos, j);
-            x = pj.x; y = pj.y; z = pj.z;
+            const double3 pj = load_scalar3_of4(a.p.pos, sj[r]);
+            sxv[r] = pj.x; syv[r] = pj.y; szv[r] = pj.z;
             }
         else
             {
-            const double4 pj = load_scalar4(a.p.pos, j);
-            x = pj.x; y = pj.y; z = pj.z;
-            s_t[s + 1] = type_from_w(pj.w);
+            const double4 pj = load_scalar4(a.p.pos, sj[r]);
+            sxv[r] = pj.x; syv[r] = pj.y; szv[r] = pj.z;
+            stv[r] = type_from_w(pj.w);
             }
-        if (!a.p.box.triclinic)
-            {
-            if (a.p.box.px) x = __builtin_fma(-a.p.box.Lx, rint((x - c.x) * a.p.box.Lxinv), x);
-            if (a.p.box.py) y = __builtin_fma(-a.p.box.Ly, rint((y - c.y) * a.p.box.Lyinv), y);
-            if (a.p.box.pz) z = __builtin_fma(-a.p.box.Lz, rint((z - c.z) * a.p.box.Lzinv), z);
-            }
-        s_x[s + 1] = x; s_y[s + 1] = y; s_z[s + 1] = z;
         }
+#ifdef AZP_TIMELINE
+    __builtin_amdgcn_s_waitcnt(0);
+    tl_tc = __builtin_amdgcn_s_memrealtime();
+#endif
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r)
+        {
+        const uint32_t sidx = (uint32_t)r * 256u + tid;
+        if (sidx < n_stage)
+            {
+            double x = sxv[r], y = syv[r], z = szv[r];
+            if (!a.p.box.triclinic)
+                {
+                if (a.p.box.px) x = __builtin_fma(-a.p.box.Lx, rint((x - c.x) * a.p.box.Lxinv), x);
+                if (a.p.box.py) y = __builtin_fma(-a.p.box.Ly, rint((y - c.y) * a.p.box.Lyinv), y);
+                if (a.p.box.pz) z = __builtin_fma(-a.p.box.Lz, rint((z - c.z) * a.p.box.Lzinv), z);
+                }
+            s_x[sidx + 1] = x; s_y[sidx + 1] = y; s_z[sidx + 1] = z;
+            if (!SINGLE)
+                s_t[sidx + 1] = stv[r];
+            }
+        }
+    }
 
     // ---- this lane's particle, in the same image frame ----
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63; // wave id: scalar
@@ -325,7 +398,17 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
         pi = make_double3(x, y, z);
         typei = type_from_w(p.w);
         }
+#ifdef AZP_TIMELINE
+    __builtin_amdgcn_s_waitcnt(0);
+    tl_td = __builtin_amdgcn_s_memrealtime();
+#endif
     const bool wide = __syncthreads_or(lane_wide); // also publishes the staged tile
+#ifndef AZP_NO_STAGE_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef AZP_TIMELINE
+    const unsigned long long tl_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     const uint32_t slice = tile * 4 + wave;
     const uint32_t K = to_uniform(a.slice_K[slice]); // scalar trip count: the loop counter and the chunk address stay in SGPRs
@@ -348,6 +431,18 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
     if constexpr (SINGLE && !XPLOR && E::kSplitEnergy)
         pe = E::finish_split(c0, pe, n_core, n_in);
 
+#ifdef AZP_TIMELINE
+    if (lane == 0 && tile < 16384)
+        {
+        unsigned long long* t = g_timeline + (tile * 4 + wave) * 8;
+        t[4] = tl_ta; t[5] = tl_tb; t[6] = tl_tc; t[7] = tl_td;
+        if (wave == 3)
+            t[4] = __builtin_amdgcn_s_memtime() - tl_c0; // wave 3 reports shader-clock ticks over its lifetime
+        t[0] = tl_t0; t[1] = tl_t1; t[2] = __builtin_amdgcn_s_memrealtime();
+        t[3] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (31 << 11)) << 32)
+               | (unsigned)__builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));
+        }
+#endif
     fx = group_sum<TPP>(fx);
     fy = group_sum<TPP>(fy);
     fz = group_sum<TPP>(fz);

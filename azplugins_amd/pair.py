@@ -113,6 +113,18 @@ class Pair(Force):
         self._tables = dict(
             params=torch.from_numpy(raw).to(dev), rcutsq=torch.from_numpy(rc).to(dev), ronsq=torch.from_numpy(ro).to(dev)
         )
+        # optional row-ordering hint for the tile plan (azp_pair_args.d_rinnersq)
+        inner = np.zeros(T * T)
+        for i, a in enumerate(types):
+            for j, b in enumerate(types):
+                inner[i * T + j] = self._inner_radius(self.params.get_raw((a, b))) ** 2
+        if inner.any():
+            self._tables["rinnersq"] = torch.from_numpy(inner).to(dev)
+
+    def _inner_radius(self, d):
+        """Radius inside which the potential takes a (rare) short-range branch; the
+        tile plan lists such pairs first. 0 = no such branch."""
+        return 0.0
 
     def _pair_args(self):
         st = self._state
@@ -130,6 +142,8 @@ class Pair(Force):
         a.d_head_list = nl.head_list.data_ptr()
         a.d_rcutsq = self._tables["rcutsq"].data_ptr()
         a.d_ronsq = self._tables["ronsq"].data_ptr()
+        if "rinnersq" in self._tables:
+            a.d_rinnersq = self._tables["rinnersq"].data_ptr()
         a.size_nlist = nl.size
         a.ntypes = len(st.types)
         a.shift_mode = _SHIFT[self._mode]
@@ -254,6 +268,11 @@ class PerturbedLennardJones(Pair):
         v = [C.c_double() for _ in range(3)]
         _lib.lib().azp_plj_params_unpack(raw.ctypes.data, *[C.byref(x) for x in v])
         return dict(epsilon=v[0].value, sigma=v[1].value, attraction_scale_factor=v[2].value)
+
+    def _inner_radius(self, d):
+        # the WCA core (r < 2^(1/6) sigma), plus the distance a pair can close before
+        # the next neighbor-list rebuild
+        return 2.0 ** (1.0 / 6.0) * d["sigma"] + self.nlist.buffer
 
 
 class DPDGeneralWeight(Pair):

@@ -140,6 +140,12 @@ typedef struct azp_pair_args
     double r_list_max;           /* optional: upper bound on the separation of any
                                     listed pair (r_cut_max + 2 r_buff); lets interior
                                     particles skip the minimum-image step. 0 = unknown. */
+    const double* d_rinnersq;    /* optional, read by azp_pair_plan_build only: ntypes^2
+                                    inner radii^2. Listed pairs closer than this when the
+                                    plan is built are placed first in their rows, so that
+                                    an evaluator's short-range branch (PerturbedLJ: the WCA
+                                    core, r < 2^(1/6) sigma) is confined to the first chunks
+                                    of a row. Ordering hint only; NULL = none.           */
     } azp_pair_args;
 
 int azp_pair_forces_perturbed_lennard_jones(const azp_pair_args* args, const azp_plj_params* d_params, void* stream);
