@@ -119,21 +119,28 @@ struct EvalPLJ
     // true when the pair needs eval_split's core/tail blend; eval_split_tail is valid
     // for every pair of a batch in which no lane saw a core pair (wave-uniform test)
     static __device__ __forceinline__ bool in_core(const Coeff& c, double rsq) { return rsq < c.wca_rsq; }
-    static __device__ __forceinline__ void eval_split_tail(const Coeff& c, double rsq, double& force_divr, double& pe_raw,
-                                                           uint32_t& n_in)
+    // Tail-only form. The energy of a tail pair is lam (lj1 r6inv^2 - lj2 r6inv) with the
+    // same constants for every pair, so only S2 = sum r6inv^2 and S1 = sum r6inv are
+    // accumulated (2 ops instead of 3) and combined in finish_split; the pairs inside
+    // the cutoff are counted only when the energy shift is non-zero (wave-uniform).
+    static __device__ __forceinline__ void eval_split_tail(const Coeff& c, double rsq, double& force_divr, double& s1,
+                                                           double& s2, uint32_t& n_in, bool count_in)
         {
         const bool in = rsq < c.rcutsq;
         const double x = fast_rcp1(rsq);
         const double r2inv = __hiloint2double(in ? __double2hiint(x) : 0, __double2loint(x));
         const double r6inv = r2inv * r2inv * r2inv;
         force_divr = r2inv * r6inv * __builtin_fma(c.c12_lam, r6inv, -c.c6_lam);
-        const double e = r6inv * __builtin_fma(c.lj1, r6inv, -c.lj2);
-        pe_raw = __builtin_fma(e, c.lam, pe_raw);
-        n_in += in ? 1u : 0u;
+        s2 = __builtin_fma(r6inv, r6inv, s2);
+        s1 += r6inv;
+        if (count_in)
+            n_in += in ? 1u : 0u;
         }
-    static __device__ __forceinline__ double finish_split(const Coeff& c, double pe_raw, uint32_t n_wca, uint32_t n_in)
+    static __device__ __forceinline__ double finish_split(const Coeff& c, double pe_raw, double s1, double s2, uint32_t n_wca,
+                                                          uint32_t n_in)
         {
-        return __builtin_fma((double)n_wca, c.wca_minus_tail, __builtin_fma((double)n_in, c.tail_add, pe_raw));
+        const double tail = c.lam * __builtin_fma(c.lj1, s2, -c.lj2 * s1);
+        return __builtin_fma((double)n_wca, c.wca_minus_tail, __builtin_fma((double)n_in, c.tail_add, pe_raw + tail));
         }
     };
 

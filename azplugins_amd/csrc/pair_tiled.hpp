@@ -93,7 +93,7 @@ __device__ __forceinline__ void tile_compute(const TileBatch& b, const TiledKArg
                                              const typename E::Coeff* __restrict__ s_coeff,
                                              const double* __restrict__ s_ronsq, const typename E::Coeff& c0, double ronsq0,
                                              double rcutsq_max, const double3& pi, int typei, double& fx, double& fy,
-                                             double& fz, double& pe, double (&v)[6], uint32_t& n_core, uint32_t& n_in)
+                                             double& fz, double& pe, double (&v)[6], uint32_t& n_core, uint32_t& n_in, double (&es)[2])
     {
     typedef typename E::Coeff Coeff;
     constexpr int NB = AZP_TILE_BATCH;
@@ -117,7 +117,7 @@ __device__ __forceinline__ void tile_compute(const TileBatch& b, const TiledKArg
 #endif
     if (!__any(any_in))
         return;
-    if constexpr (SPLIT && !VIRIAL)
+    if constexpr (SPLIT)
         {
         // rows list the pairs inside the evaluator's core first (plan hint), so beyond
         // the first chunks no lane of the wave has one and the cheaper tail-only form
@@ -132,10 +132,20 @@ __device__ __forceinline__ void tile_compute(const TileBatch& b, const TiledKArg
             for (int e = 0; e < NB; ++e)
                 {
                 double force_divr;
-                E::eval_split_tail(c0, rsq[e], force_divr, pe, n_in);
+                E::eval_split_tail(c0, rsq[e], force_divr, es[0], es[1], n_in, c0.tail_add != 0.0);
                 fx = __builtin_fma(dx[e], force_divr, fx);
                 fy = __builtin_fma(dy[e], force_divr, fy);
                 fz = __builtin_fma(dz[e], force_divr, fz);
+                if (VIRIAL)
+                    {
+                    const double fxx = force_divr * dx[e], fyy = force_divr * dy[e];
+                    v[0] = __builtin_fma(fxx, dx[e], v[0]);
+                    v[1] = __builtin_fma(fxx, dy[e], v[1]);
+                    v[2] = __builtin_fma(fxx, dz[e], v[2]);
+                    v[3] = __builtin_fma(fyy, dy[e], v[3]);
+                    v[4] = __builtin_fma(fyy, dz[e], v[4]);
+                    v[5] = __builtin_fma(force_divr * dz[e], dz[e], v[5]);
+                    }
                 }
             return;
             }
@@ -191,7 +201,7 @@ __device__ __forceinline__ void tiled_loop(const TiledKArgs& a, const char* bx, 
                                            const double* __restrict__ s_ronsq, const typename E::Coeff& c0, double ronsq0,
                                            double rcutsq_max, const char* __restrict__ slice_base, uint32_t lane_off, uint32_t K, double3 pi,
                                            int typei, double& fx, double& fy, double& fz, double& pe, double (&v)[6], uint32_t& n_core,
-                                           uint32_t& n_in)
+                                           uint32_t& n_in, double (&es)[2])
     {
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
     // chunk kk of this lane: uniform base + kk KiB (scalar) + 16 lane (one VGPR)
@@ -213,11 +223,11 @@ __device__ __forceinline__ void tiled_loop(const TiledKArgs& a, const char* bx, 
         const uint4 un2 = chunk_at((kk + 2 < K) ? kk + 2 : K - 1);
         tile_gather<CAP, 1>(B, u, bx);
         __builtin_amdgcn_sched_barrier(0);
-        tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(A, a, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, pi, typei, fx, fy, fz, pe, v, n_core, n_in);
+        tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(A, a, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, pi, typei, fx, fy, fz, pe, v, n_core, n_in, es);
         __builtin_amdgcn_sched_barrier(0);
         tile_gather<CAP, 0>(A, un, bx); // when kk + 1 == K: gathered, never used
         __builtin_amdgcn_sched_barrier(0);
-        tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(B, a, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, pi, typei, fx, fy, fz, pe, v, n_core, n_in);
+        tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(B, a, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, pi, typei, fx, fy, fz, pe, v, n_core, n_in, es);
         __builtin_amdgcn_sched_barrier(0);
         u = un;
         un = un2;
@@ -234,12 +244,12 @@ __device__ __forceinline__ void tiled_loop(const TiledKArgs& a, const char* bx, 
         const uint4 u3 = (kk + 3 < K) ? chunk_at(kk + 3) : zero4;
         tile_gather<CAP, 0>(B, u1, bx);
         __builtin_amdgcn_sched_barrier(0);
-        tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(A, a, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, pi, typei, fx, fy, fz, pe, v, n_core, n_in);
+        tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(A, a, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, pi, typei, fx, fy, fz, pe, v, n_core, n_in, es);
         __builtin_amdgcn_sched_barrier(0);
         tile_gather<CAP, 0>(A, u2, bx);
         __builtin_amdgcn_sched_barrier(0);
         if (kk + 1 < K)
-            tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(B, a, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, pi, typei, fx, fy, fz, pe, v, n_core, n_in);
+            tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(B, a, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, pi, typei, fx, fy, fz, pe, v, n_core, n_in, es);
         __builtin_amdgcn_sched_barrier(0);
         u1 = u3;
         }
@@ -420,16 +430,17 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
     double fx = 0.0, fy = 0.0, fz = 0.0, pe = 0.0;
     double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     uint32_t n_core = 0, n_in = 0;
+    double es[2] = {0.0, 0.0}; // tail-path energy sums (EvalPLJ::eval_split_tail)
     const char* bx = reinterpret_cast<const char*>(s_x);
     const char* bt = reinterpret_cast<const char*>(s_t);
     if (wide)
         tiled_loop<E, TPP, CAP, VIRIAL, SINGLE, XPLOR, true>(a, bx, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, slice_base, lane_off, K, pi,
-                                                            typei, fx, fy, fz, pe, v, n_core, n_in);
+                                                            typei, fx, fy, fz, pe, v, n_core, n_in, es);
     else
         tiled_loop<E, TPP, CAP, VIRIAL, SINGLE, XPLOR, false>(a, bx, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, slice_base, lane_off, K, pi,
-                                                             typei, fx, fy, fz, pe, v, n_core, n_in);
+                                                             typei, fx, fy, fz, pe, v, n_core, n_in, es);
     if constexpr (SINGLE && !XPLOR && E::kSplitEnergy)
-        pe = E::finish_split(c0, pe, n_core, n_in);
+        pe = E::finish_split(c0, pe, es[0], es[1], n_core, n_in);
 
 #ifdef AZP_TIMELINE
     if (lane == 0 && tile < 16384)
