@@ -302,6 +302,23 @@ template<bool FILL, bool MI> __global__ void __launch_bounds__(NL_THREADS) nlist
         }
     }
 
+__global__ void __launch_bounds__(256) distance_check_kernel(uint32_t n, const double* __restrict__ pos,
+                                                             const double* __restrict__ pos0, BoxDev box, double max_dist_sq,
+                                                             uint32_t* __restrict__ flag)
+    {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool moved = false;
+    if (i < n)
+        {
+        const double3 p = load_scalar3_of4(pos, i), q = load_scalar3_of4(pos0, i);
+        double dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+        min_image(box, dx, dy, dz);
+        moved = dx * dx + dy * dy + dz * dz > max_dist_sq;
+        }
+    if (__any(moved) && (threadIdx.x & 63) == 0)
+        atomicOr(flag, 1u);
+    }
+
 static int check_nlist_args(const azp_nlist_args* a)
     {
     if (!a || !a->d_pos || a->n_total < a->N || a->ntypes == 0)
@@ -397,3 +414,16 @@ static int nlist_scan(const azp_nlist_args* args, void* stream, bool fill)
 
 extern "C" int azp_nlist_count(const azp_nlist_args* args, void* stream) { return nlist_scan(args, stream, false); }
 extern "C" int azp_nlist_fill(const azp_nlist_args* args, void* stream) { return nlist_scan(args, stream, true); }
+
+extern "C" int azp_nlist_distance_check(uint32_t n, const double* d_pos, const double* d_pos_at_build, const azp_box* box,
+                                        double max_dist_sq, uint32_t* d_flag, void* stream)
+    {
+    using namespace azp;
+    if (!d_pos || !d_pos_at_build || !box || !d_flag || !(max_dist_sq >= 0.0))
+        return AZP_ERROR_INVALID_ARGUMENT;
+    if (n == 0)
+        return AZP_SUCCESS;
+    hipLaunchKernelGGL(distance_check_kernel, dim3((n + 255u) / 256u), dim3(256), 0, static_cast<hipStream_t>(stream), n, d_pos,
+                       d_pos_at_build, make_box_dev(*box), max_dist_sq, d_flag);
+    return (int)hipGetLastError();
+    }

@@ -63,20 +63,25 @@ class Cell(NeighborList):
         if not force and self.nlist is not None:
             if self._built_generation == state.position_generation:
                 return
-            if self._max_displacement(state) <= 0.5 * self.buffer:
+            if not self._moved_too_far(state):
                 self._built_generation = state.position_generation
                 return
         self._build(state)
         self._built_generation = state.position_generation
 
-    def _max_displacement(self, state):
+    def _moved_too_far(self, state):
+        """One kernel + a 4-byte readback (HOOMD's distance check)."""
         import torch
 
-        d = state.pos[: state.n_max, :3] - self._pos_at_build
-        L = torch.tensor(state.box.L, dtype=d.dtype, device=d.device)
-        per = torch.tensor([1.0 if p else 0.0 for p in state.box.periodic], dtype=d.dtype, device=d.device)
-        d = d - per * L * torch.round(d / L)
-        return float((d * d).sum(dim=1).max().sqrt().item())
+        if getattr(self, "_flag", None) is None or self._flag.device != state.pos.device:
+            self._flag = torch.zeros(1, dtype=torch.int32, device=state.pos.device)
+        self._flag.zero_()
+        box = state.box.to_c()
+        stream = torch.cuda.current_stream(state.device).cuda_stream
+        _lib.check(_lib.lib().azp_nlist_distance_check(state.n_max, state.pos.data_ptr(), self._pos_at_build.data_ptr(),
+                                                       C.byref(box), (0.5 * self.buffer) ** 2, self._flag.data_ptr(), stream),
+                   "azp_nlist_distance_check")
+        return bool(self._flag.item())
 
     def _build(self, state):
         import torch
@@ -170,6 +175,6 @@ class Cell(NeighborList):
         self._row_capacity = (int(self.max_neigh * 1.06) + 4 + 7) // 8 * 8
 
         self.n_neigh, self.head_list, self.nlist, self.size = n_neigh, head, nlist, size
-        self._pos_at_build = state.pos[:n_total, :3].clone()
+        self._pos_at_build = state.pos[:n_total].clone()
         self.num_builds += 1
         self._keep = (rlistsq, cell_of, cell_sorted, order, cell_start, keep)

@@ -73,8 +73,17 @@ class Simulation:
         import torch
 
         st = self.state
-        st.net_force.zero_()
-        for f in self.operations.integrator.forces:
+        forces = self.operations.integrator.forces
+        if len(forces) == 1:
+            # a single force: its own array is the net force (no 32 MB zero + add per step)
+            forces[0].compute(self.timestep)
+            st.net_force = forces[0].force_tensor
+            return
+        if st.net_force.shape[0] != st.N or any(st.net_force is f.force_tensor for f in forces):
+            st.net_force = torch.zeros((st.N, 4), dtype=torch.float64, device=st.device)
+        else:
+            st.net_force.zero_()
+        for f in forces:
             f.compute(self.timestep)
             st.net_force += f.force_tensor
 
@@ -101,10 +110,12 @@ class Simulation:
         stream = torch.cuda.current_stream(st.device).cuda_stream
         for _ in range(steps):
             # velocity Verlet (libazp kernels): v += a dt/2, x += v dt, wrap | forces | v += a dt/2
+            a.d_net_force = st.net_force.data_ptr()
             _lib.check(lib.azp_integrate_nve_step_one(C.byref(a), stream), "azp_integrate_nve_step_one")
             st.position_generation += 1
             self.timestep += 1
             self._compute_forces()
+            a.d_net_force = st.net_force.data_ptr()
             _lib.check(lib.azp_integrate_nve_step_two(C.byref(a), stream), "azp_integrate_nve_step_two")
 
     def kinetic_temperature(self):

@@ -318,6 +318,12 @@ int azp_nlist_cell_bounds(const azp_nlist_args* args, void* stream);
 int azp_nlist_count(const azp_nlist_args* args, void* stream);
 int azp_nlist_fill(const azp_nlist_args* args, void* stream);
 
+/* Rebuild criterion (HOOMD NeighborList::distanceCheck restated): sets *d_flag to 1
+ * when any of the n particles moved farther than sqrt(max_dist_sq) from its position
+ * at the last build (minimum image in `box`); the caller zeroes *d_flag beforehand. */
+int azp_nlist_distance_check(uint32_t n, const double* d_pos, const double* d_pos_at_build, const azp_box* box,
+                             double max_dist_sq, uint32_t* d_flag, void* stream);
+
 /* ---- one-body harmonic barriers ----
  * Replaces the reference's own kernel driver
  *   azplugins::gpu::compute_harmonic_barrier<Evaluator>(...)   (src/HarmonicBarrierGPU.cuh:49-140,

@@ -1,0 +1,49 @@
+"""End-to-end MD step rate on the north-star system: velocity-Verlet NVE with the
+PerturbedLJ pair force, neighbor-list rebuilds on HOOMD's displacement criterion
+and tile-plan rebuilds included -- what bench.py's static-list metric leaves out.
+
+    python tools/md_bench.py [--steps 400] [--kT 1.0] [--dt 0.005] [--no-plan]
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import azplugins_amd as azp
+from azplugins_amd import synthetic as syn
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=400)
+ap.add_argument("--kT", type=float, default=1.0)
+ap.add_argument("--dt", type=float, default=0.005)
+ap.add_argument("--ncell", type=int, default=64)
+ap.add_argument("--no-plan", action="store_true")
+args = ap.parse_args()
+
+cfg = syn.config_north_star(args.ncell)
+N = cfg["xyz"].shape[0]
+sim = azp.Simulation(device="cuda:0", seed=1)
+sim.create_state_from_snapshot(azp.Snapshot.from_arrays(cfg["xyz"], cfg["L"]))
+nl = azp.nlist.Cell(buffer=cfg["r_buff"])
+pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=cfg["r_cut"])
+pot.params[("A", "A")] = cfg["params"]
+pot.use_plan = not args.no_plan
+sim.operations.integrator = azp.Integrator(dt=args.dt, forces=[pot], methods=[azp.ConstantVolume()])
+sim.run(0)
+sim.thermalize_particle_momenta(args.kT, seed=7)
+sim.run(50)  # melt the lattice a little, warm the allocator
+torch.cuda.synchronize()
+b0 = nl.num_builds
+e0 = pot.energy + 0.5 * float((sim.state.vel[:N, 3] * (sim.state.vel[:N, :3] ** 2).sum(1)).sum())
+t0 = time.perf_counter()
+sim.run(args.steps)
+torch.cuda.synchronize()
+t = time.perf_counter() - t0
+e1 = pot.energy + 0.5 * float((sim.state.vel[:N, 3] * (sim.state.vel[:N, :3] ** 2).sum(1)).sum())
+builds = nl.num_builds - b0
+print("N=%d  %d steps in %.3f s: %.3f ms/step, %.3e particle-steps/s; %d neighbor-list (+plan) rebuilds = one per %.1f steps; "
+      "kT=%.3f; energy drift %.2e per particle" % (N, args.steps, t, 1e3 * t / args.steps, N * args.steps / t, builds,
+                                                   args.steps / max(builds, 1), sim.kinetic_temperature(), (e1 - e0) / N))

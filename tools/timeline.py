@@ -76,3 +76,32 @@ for x in range(8):
     m = xcc == x
     if m.any():
         print("xcc %d: %4d tiles, last finish %.1f us" % (x, m.sum(), (wg_end[m].max() - origin) * us))
+
+# ---- would a longest-first tile order shorten the tail? ----
+nn = nl.n_neigh.cpu().numpy().astype(np.int64)
+K = np.ceil(nn.reshape(n_tiles, 4, 64).max(axis=2) / 8.0)  # chunks per slice
+work = K.sum(axis=1)
+print("chunks per tile: mean %.1f  min %d  max %d; corr(duration, chunks) = %.2f" % (
+    work.mean(), work.min(), work.max(), np.corrcoef(dur, work)[0, 1]))
+order_start = np.argsort(wg_start)
+print("duration by launch order (quarters): " + " ".join("%.1f" % dur[order_start[q * 1024:(q + 1) * 1024]].mean() for q in range(4)))
+
+
+def makespan(durs, slots=128):
+    import heapq
+    h = [0.0] * slots
+    heapq.heapify(h)
+    for d in durs:
+        heapq.heappush(h, heapq.heappop(h) + d)
+    return max(h)
+
+
+for x in range(8):
+    m = np.where(xcc == x)[0]
+    if m.size == 0:
+        continue
+    d = dur[m]
+    print("xcc %d: list-scheduling makespan in launch order %.1f us, longest-first %.1f us, ideal %.1f us" % (
+        x, makespan(d[np.argsort(wg_start[m])]), makespan(np.sort(d)[::-1]), d.sum() / 128))
+    if x >= 1:
+        break
