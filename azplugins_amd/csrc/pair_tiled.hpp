@@ -117,37 +117,30 @@ __device__ __forceinline__ void tile_compute(const TileBatch& b, const TiledKArg
 #endif
     if (!__any(any_in))
         return;
+    double fd[NB]; // force / r of the batch (SPLIT: filled by one of two forms of the evaluator)
     if constexpr (SPLIT)
         {
         // rows list the pairs inside the evaluator's core first (plan hint), so beyond
         // the first chunks no lane of the wave has one and the cheaper tail-only form
-        // applies to the whole batch (exact: tested on the actual separations)
+        // applies to the whole batch (exact: tested on the actual separations). Both
+        // branches only produce fd[]; the accumulation below is shared, so the force
+        // accumulators are not live-out of either branch (no register copies at the join).
         bool any_core = false;
 #pragma unroll
         for (int e = 0; e < NB; ++e)
             any_core = any_core || E::in_core(c0, rsq[e]);
         if (!__any(any_core))
             {
+            const bool count_in = c0.tail_add != 0.0;
 #pragma unroll
             for (int e = 0; e < NB; ++e)
-                {
-                double force_divr;
-                E::eval_split_tail(c0, rsq[e], force_divr, es[0], es[1], n_in, c0.tail_add != 0.0);
-                fx = __builtin_fma(dx[e], force_divr, fx);
-                fy = __builtin_fma(dy[e], force_divr, fy);
-                fz = __builtin_fma(dz[e], force_divr, fz);
-                if (VIRIAL)
-                    {
-                    const double fxx = force_divr * dx[e], fyy = force_divr * dy[e];
-                    v[0] = __builtin_fma(fxx, dx[e], v[0]);
-                    v[1] = __builtin_fma(fxx, dy[e], v[1]);
-                    v[2] = __builtin_fma(fxx, dz[e], v[2]);
-                    v[3] = __builtin_fma(fyy, dy[e], v[3]);
-                    v[4] = __builtin_fma(fyy, dz[e], v[4]);
-                    v[5] = __builtin_fma(force_divr * dz[e], dz[e], v[5]);
-                    }
-                }
-            return;
+                E::eval_split_tail(c0, rsq[e], fd[e], es[0], es[1], n_in, count_in);
+            }
+        else
+            {
+#pragma unroll
+            for (int e = 0; e < NB; ++e)
+                E::eval_split(c0, rsq[e], fd[e], pe, n_core, n_in);
             }
         }
 #pragma unroll
@@ -155,7 +148,7 @@ __device__ __forceinline__ void tile_compute(const TileBatch& b, const TiledKArg
         {
         double force_divr, pair_eng = 0.0;
         if constexpr (SPLIT)
-            E::eval_split(c0, rsq[e], force_divr, pe, n_core, n_in);
+            force_divr = fd[e];
         else if (SINGLE)
             {
             const bool evaluated = E::eval(c0, rsq[e], force_divr, pair_eng);
