@@ -51,14 +51,15 @@ template<uint32_t HC> __device__ __forceinline__ uint32_t plan_hash(uint32_t j)
 // Neighboring particles list mostly the same neighbors, so ~96 % of the inserts
 // find their key already present: probe with a plain read first and fall back to
 // the (slower) atomic only on an empty slot.
-template<uint32_t HC> __device__ __forceinline__ bool plan_insert(uint32_t* table, uint32_t j)
+// The table holds (key, slot) pairs so that a lookup is one 8-byte LDS read.
+template<uint32_t HC> __device__ __forceinline__ bool plan_insert(uint2* table, uint32_t j)
     {
     uint32_t h = plan_hash<HC>(j);
     for (uint32_t probe = 0; probe < HC; ++probe)
         {
-        uint32_t cur = table[h];
+        uint32_t cur = table[h].x;
         if (cur == PLAN_EMPTY)
-            cur = atomicCAS(&table[h], PLAN_EMPTY, j);
+            cur = atomicCAS(&table[h].x, PLAN_EMPTY, j);
         if (cur == PLAN_EMPTY || cur == j)
             return true;
         h = (h + 1) & (HC - 1);
@@ -67,12 +68,25 @@ template<uint32_t HC> __device__ __forceinline__ bool plan_insert(uint32_t* tabl
     }
 
 // Position of key j in the table (j is known to be present).
-template<uint32_t HC> __device__ __forceinline__ uint32_t plan_find(const uint32_t* table, uint32_t j)
+template<uint32_t HC> __device__ __forceinline__ uint32_t plan_find(const uint2* table, uint32_t j)
     {
     uint32_t h = plan_hash<HC>(j);
-    while (table[h] != j)
+    while (table[h].x != j)
         h = (h + 1) & (HC - 1);
     return h;
+    }
+
+// Slot of key j (j is known to be present and its slot published).
+template<uint32_t HC> __device__ __forceinline__ uint32_t plan_slot(const uint2* table, uint32_t j)
+    {
+    uint32_t h = plan_hash<HC>(j);
+    uint2 kv = table[h];
+    while (kv.x != j)
+        {
+        h = (h + 1) & (HC - 1);
+        kv = table[h];
+        }
+    return kv.y;
     }
 
 // Chunk count per slice: K = ceil(max row length in the slice / (8 * TPP)).
@@ -116,9 +130,8 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
     constexpr int ITERS = PLAN_ROWBUF / 64;
     constexpr int NT = PLAN_BUILD_THREADS;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    uint32_t* table = reinterpret_cast<uint32_t*>(s_raw);          // HC keys
-    uint16_t* slot_of = reinterpret_cast<uint16_t*>(table + HC);   // HC
-    uint16_t* w_rowbuf = slot_of + HC;                             // PLAN_BUILD_WAVES x PLAN_ROWBUF
+    uint2* table = reinterpret_cast<uint2*>(s_raw);                // HC (key, slot) pairs
+    uint16_t* w_rowbuf = reinterpret_cast<uint16_t*>(table + HC);  // PLAN_BUILD_WAVES x PLAN_ROWBUF
     // list[4096] (sort scratch) and the staged positions (stage_stride slots) share
     // one region: the list is dead once slots and positions are published
     uint32_t* list = reinterpret_cast<uint32_t*>(w_rowbuf + PLAN_BUILD_WAVES * PLAN_ROWBUF);
@@ -126,7 +139,7 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
     // (x, y, z, type): they only feed the near/far ordering hint, never a force
     float4* s_p = reinterpret_cast<float4*>(list);
     __shared__ uint32_t s_n, s_overflow;
-    __shared__ double s_rcutsq[64]; // up to 8 types cached; more types read the global table
+    __shared__ float s_rcutsq[64], s_rinnersq[64]; // up to 8 types cached; more types read the global tables
     // bank-aware row ordering (TPP == 1): per wave 32 (part, bank) counters, 2 misfit
     // counters and the list of unclaimed positions
     __shared__ uint32_t s_bank_cnt[PLAN_BUILD_WAVES][52];
@@ -140,12 +153,18 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
     const bool rc_cached = a.ntypes <= 8;
 
     for (uint32_t t = tid; t < HC; t += NT)
-        table[t] = PLAN_EMPTY;
+        table[t] = make_uint2(PLAN_EMPTY, 0u);
     for (uint32_t t = tid; t < 4096; t += NT)
         list[t] = PLAN_EMPTY;
     if (tid == 0) { s_n = 0; s_overflow = 0; }
     if (rc_cached && tid < a.ntypes * a.ntypes)
-        s_rcutsq[tid] = a.rcutsq[tid];
+        {
+        s_rcutsq[tid] = (float)a.rcutsq[tid];
+        s_rinnersq[tid] = a.rinnersq ? (float)a.rinnersq[tid] : 0.f;
+        }
+    // the classification is an ordering hint: single precision is enough
+    const float bLx = (float)a.box.Lx, bLy = (float)a.box.Ly, bLz = (float)a.box.Lz;
+    const float bLxi = (float)a.box.Lxinv, bLyi = (float)a.box.Lyinv, bLzi = (float)a.box.Lzinv;
     __syncthreads();
 
     // ---- hash-set of all neighbor indices of the tile: every wave takes rows
@@ -175,7 +194,7 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
     // ---- compact + sort ----
     for (uint32_t t = tid; t < HC; t += NT)
         {
-        const uint32_t j = table[t];
+        const uint32_t j = table[t].x;
         if (j != PLAN_EMPTY)
             {
             const uint32_t slot = atomicAdd(&s_n, 1u);
@@ -247,7 +266,7 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
             {
             const uint32_t j = list[t];
             stage[t] = j;
-            slot_of[plan_find<HC>(table, j)] = (uint16_t)t;
+            table[plan_find<HC>(table, j)].y = t;
             const double4 pj = load_scalar4(a.pos, j);
             double dx = pj.x - c.x, dy = pj.y - c.y, dz = pj.z - c.z;
             min_image(a.box, dx, dy, dz);
@@ -318,14 +337,25 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
                 bool near = false, core = false;
                 if (jj[it] != PLAN_EMPTY)
                     {
-                    const uint32_t sidx = slot_of[plan_find<HC>(table, jj[it])];
+                    const uint32_t sidx = plan_slot<HC>(table, jj[it]);
                     const float4 q = s_p[sidx];
-                    double dx = xi - q.x, dy = yi - q.y, dz = zi - q.z;
-                    min_image(a.box, dx, dy, dz);
-                    const double rsq = dx * dx + dy * dy + dz * dz;
+                    float dx = xi - q.x, dy = yi - q.y, dz = zi - q.z;
+                    if (!a.box.triclinic)
+                        {
+                        if (a.box.pz) dz = __builtin_fmaf(-bLz, rintf(dz * bLzi), dz);
+                        if (a.box.py) dy = __builtin_fmaf(-bLy, rintf(dy * bLyi), dy);
+                        if (a.box.px) dx = __builtin_fmaf(-bLx, rintf(dx * bLxi), dx);
+                        }
+                    else
+                        {
+                        double ddx = dx, ddy = dy, ddz = dz;
+                        min_image(a.box, ddx, ddy, ddz);
+                        dx = (float)ddx; dy = (float)ddy; dz = (float)ddz;
+                        }
+                    const float rsq = dx * dx + dy * dy + dz * dz;
                     const uint32_t tp = trow + (uint32_t)__float_as_int(q.w);
-                    const bool in = rsq < (rc_cached ? s_rcutsq[tp] : a.rcutsq[tp]);
-                    core = in && a.rinnersq && rsq < a.rinnersq[tp];
+                    const bool in = rsq < (rc_cached ? s_rcutsq[tp] : (float)a.rcutsq[tp]);
+                    core = in && rsq < (rc_cached ? s_rinnersq[tp] : (a.rinnersq ? (float)a.rinnersq[tp] : 0.f));
                     near = in && !core;
                     enc[it] = (((sidx + 1u) * 8u) << 2) | (core ? 0u : (near ? 1u : 2u));
                     }
@@ -468,7 +498,7 @@ static void plan_free(PairPlan& p)
 static size_t plan_lds_bytes(uint32_t hc, uint32_t stride)
     {
     const size_t shared_region = std::max<size_t>(4096 * 4, (size_t)stride * 16);
-    return (size_t)hc * 4 + (size_t)hc * 2 + (size_t)PLAN_BUILD_WAVES * PLAN_ROWBUF * 2 + shared_region;
+    return (size_t)hc * 8 + (size_t)PLAN_BUILD_WAVES * PLAN_ROWBUF * 2 + shared_region;
     }
 
 template<int TPP, uint32_t HC> static hipError_t launch_plan_build(const PlanKArgs& k, uint32_t n_tiles, hipStream_t s)
