@@ -51,15 +51,14 @@ template<uint32_t HC> __device__ __forceinline__ uint32_t plan_hash(uint32_t j)
 // Neighboring particles list mostly the same neighbors, so ~96 % of the inserts
 // find their key already present: probe with a plain read first and fall back to
 // the (slower) atomic only on an empty slot.
-// The table holds (key, slot) pairs so that a lookup is one 8-byte LDS read.
-template<uint32_t HC> __device__ __forceinline__ bool plan_insert(uint2* table, uint32_t j)
+template<uint32_t HC> __device__ __forceinline__ bool plan_insert(uint32_t* table, uint32_t j)
     {
     uint32_t h = plan_hash<HC>(j);
     for (uint32_t probe = 0; probe < HC; ++probe)
         {
-        uint32_t cur = table[h].x;
+        uint32_t cur = table[h];
         if (cur == PLAN_EMPTY)
-            cur = atomicCAS(&table[h].x, PLAN_EMPTY, j);
+            cur = atomicCAS(&table[h], PLAN_EMPTY, j);
         if (cur == PLAN_EMPTY || cur == j)
             return true;
         h = (h + 1) & (HC - 1);
@@ -68,25 +67,12 @@ template<uint32_t HC> __device__ __forceinline__ bool plan_insert(uint2* table, 
     }
 
 // Position of key j in the table (j is known to be present).
-template<uint32_t HC> __device__ __forceinline__ uint32_t plan_find(const uint2* table, uint32_t j)
+template<uint32_t HC> __device__ __forceinline__ uint32_t plan_find(const uint32_t* table, uint32_t j)
     {
     uint32_t h = plan_hash<HC>(j);
-    while (table[h].x != j)
+    while (table[h] != j)
         h = (h + 1) & (HC - 1);
     return h;
-    }
-
-// Slot of key j (j is known to be present and its slot published).
-template<uint32_t HC> __device__ __forceinline__ uint32_t plan_slot(const uint2* table, uint32_t j)
-    {
-    uint32_t h = plan_hash<HC>(j);
-    uint2 kv = table[h];
-    while (kv.x != j)
-        {
-        h = (h + 1) & (HC - 1);
-        kv = table[h];
-        }
-    return kv.y;
     }
 
 // Chunk count per slice: K = ceil(max row length in the slice / (8 * TPP)).
@@ -130,8 +116,12 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
     constexpr int ITERS = PLAN_ROWBUF / 64;
     constexpr int NT = PLAN_BUILD_THREADS;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    uint2* table = reinterpret_cast<uint2*>(s_raw);                // HC (key, slot) pairs
-    uint16_t* w_rowbuf = reinterpret_cast<uint16_t*>(table + HC);  // PLAN_BUILD_WAVES x PLAN_ROWBUF
+    // keys and slots in separate arrays: (key, slot) pairs would save one dependent
+    // LDS read per lookup but cost 8 KiB more, which halves the occupancy once a
+    // tile stages more than 1,536 particles (a liquid, as opposed to the lattice)
+    uint32_t* table = reinterpret_cast<uint32_t*>(s_raw);          // HC keys
+    uint16_t* slot_of = reinterpret_cast<uint16_t*>(table + HC);   // HC
+    uint16_t* w_rowbuf = slot_of + HC;                             // PLAN_BUILD_WAVES x PLAN_ROWBUF
     // list[4096] (sort scratch) and the staged positions (stage_stride slots) share
     // one region: the list is dead once slots and positions are published
     uint32_t* list = reinterpret_cast<uint32_t*>(w_rowbuf + PLAN_BUILD_WAVES * PLAN_ROWBUF);
@@ -153,7 +143,7 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
     const bool rc_cached = a.ntypes <= 8;
 
     for (uint32_t t = tid; t < HC; t += NT)
-        table[t] = make_uint2(PLAN_EMPTY, 0u);
+        table[t] = PLAN_EMPTY;
     for (uint32_t t = tid; t < 4096; t += NT)
         list[t] = PLAN_EMPTY;
     if (tid == 0) { s_n = 0; s_overflow = 0; }
@@ -194,7 +184,7 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
     // ---- compact + sort ----
     for (uint32_t t = tid; t < HC; t += NT)
         {
-        const uint32_t j = table[t].x;
+        const uint32_t j = table[t];
         if (j != PLAN_EMPTY)
             {
             const uint32_t slot = atomicAdd(&s_n, 1u);
@@ -266,7 +256,7 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
             {
             const uint32_t j = list[t];
             stage[t] = j;
-            table[plan_find<HC>(table, j)].y = t;
+            slot_of[plan_find<HC>(table, j)] = (uint16_t)t;
             const double4 pj = load_scalar4(a.pos, j);
             double dx = pj.x - c.x, dy = pj.y - c.y, dz = pj.z - c.z;
             min_image(a.box, dx, dy, dz);
@@ -337,7 +327,7 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
                 bool near = false, core = false;
                 if (jj[it] != PLAN_EMPTY)
                     {
-                    const uint32_t sidx = plan_slot<HC>(table, jj[it]);
+                    const uint32_t sidx = slot_of[plan_find<HC>(table, jj[it])];
                     const float4 q = s_p[sidx];
                     float dx = xi - q.x, dy = yi - q.y, dz = zi - q.z;
                     if (!a.box.triclinic)
@@ -498,7 +488,7 @@ static void plan_free(PairPlan& p)
 static size_t plan_lds_bytes(uint32_t hc, uint32_t stride)
     {
     const size_t shared_region = std::max<size_t>(4096 * 4, (size_t)stride * 16);
-    return (size_t)hc * 8 + (size_t)PLAN_BUILD_WAVES * PLAN_ROWBUF * 2 + shared_region;
+    return (size_t)hc * 4 + (size_t)hc * 2 + (size_t)PLAN_BUILD_WAVES * PLAN_ROWBUF * 2 + shared_region;
     }
 
 template<int TPP, uint32_t HC> static hipError_t launch_plan_build(const PlanKArgs& k, uint32_t n_tiles, hipStream_t s)
@@ -632,7 +622,8 @@ static int plan_build_tpp(PairPlan& p, const azp_pair_args& args, uint32_t tpp, 
         }
     p.stage_stride_hint = p.max_stage + p.max_stage / 4 + 64;
     p.total_stage = (uint64_t)p.n_tiles * stride;
-    p.cap = p.max_stage + 1 <= 1024 ? 1024 : (p.max_stage + 1 <= 1536 ? 1536 : (p.max_stage + 1 <= 2048 ? 2048 : 2560));
+    // 1664 slots x 24 B is the most that still lets four workgroups share a CU's 160 KiB of LDS
+    p.cap = p.max_stage + 1 <= 1024 ? 1024 : (p.max_stage + 1 <= 1536 ? 1536 : (p.max_stage + 1 <= 1664 ? 1664 : (p.max_stage + 1 <= 2048 ? 2048 : 2560)));
     p.valid = true;
     return AZP_SUCCESS;
     }

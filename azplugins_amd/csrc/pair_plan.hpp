@@ -42,7 +42,7 @@ struct PairPlan
     // configuration chosen at build time
     uint32_t tpp = 0;          // lanes per particle (1, 2, 4)
     uint32_t tile = 0;         // particles per tile = 4 waves * 64 / tpp
-    uint32_t cap = 0;          // LDS slots the force kernel must provide (1024 / 1536 / 2048 / 2560)
+    uint32_t cap = 0;          // LDS slots the force kernel must provide (1024 / 1536 / 1664 / 2048 / 2560)
     // what it was built for
     uint32_t N = 0, n_max = 0;
     const uint32_t* nlist_ptr = nullptr;

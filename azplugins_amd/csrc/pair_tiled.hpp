@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
     // trips per tile instead of two per 256 staged particles -- the staging took 17 of
     // a tile's 41 us when it was written as a plain loop, tools/timeline.py).
     {
-    constexpr int ROUNDS = CAP / 256; // CAP is a multiple of 256 and n_stage < CAP
+    constexpr int ROUNDS = (CAP + 255) / 256; // n_stage < CAP
     uint32_t sj[ROUNDS];
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r)
@@ -524,6 +524,7 @@ int launch_tiled_cap(const PairPlan& plan, const azp_pair_args& args, const type
         {
     case 1024: return launch_tiled_instance<E, TPP, 1024, VIRIAL, SINGLE>(plan, args, d_params, s);
     case 1536: return launch_tiled_instance<E, TPP, 1536, VIRIAL, SINGLE>(plan, args, d_params, s);
+    case 1664: return launch_tiled_instance<E, TPP, 1664, VIRIAL, SINGLE>(plan, args, d_params, s);
     case 2048: return launch_tiled_instance<E, TPP, 2048, VIRIAL, SINGLE>(plan, args, d_params, s);
     case 2560: return launch_tiled_instance<E, TPP, 2560, VIRIAL, SINGLE>(plan, args, d_params, s);
     default: return AZP_ERROR_INVALID_ARGUMENT;

@@ -47,3 +47,13 @@ builds = nl.num_builds - b0
 print("N=%d  %d steps in %.3f s: %.3f ms/step, %.3e particle-steps/s; %d neighbor-list (+plan) rebuilds = one per %.1f steps; "
       "kT=%.3f; energy drift %.2e per particle" % (N, args.steps, t, 1e3 * t / args.steps, N * args.steps / t, builds,
                                                    args.steps / max(builds, 1), sim.kinetic_temperature(), (e1 - e0) / N))
+# force kernel alone on the final (liquid) state
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+pot.compute(0)
+ev0.record()
+for _ in range(100):
+    pot.compute(0)
+ev1.record()
+torch.cuda.synchronize()
+print("force kernel on the final state: %.4f ms/launch; mean neighbors %.1f; plan %s" % (
+    ev0.elapsed_time(ev1) / 100, nl.n_pairs / N, {k: pot.plan_info[k] for k in ("valid", "lds_slots", "max_stage")} if pot.use_plan else None))
