@@ -192,6 +192,7 @@ class HaloExchange:
 
     def transfer(self, packed):
         """all_to_all_single of the packed buffers straight into the ghost rows."""
+        import torch
         import torch.distributed as dist
 
         N = self.domain.N_local
@@ -199,8 +200,15 @@ class HaloExchange:
         for a2, buf in packed:
             ghost = a2[N:]
             if dist.is_initialized() and dist.get_world_size(self.group) > 1:
-                dist.all_to_all_single(ghost, buf, output_split_sizes=self.recv_splits,
-                                       input_split_sizes=self.send_splits, group=self.group)
+                if ghost.is_cuda and dist.get_backend(self.group) == "gloo":
+                    # rehearsal only (AZP_DIST_BACKEND=gloo): gloo has no device all-to-all
+                    recv = torch.empty(ghost.shape, dtype=ghost.dtype)
+                    dist.all_to_all_single(recv, buf.cpu(), output_split_sizes=self.recv_splits,
+                                           input_split_sizes=self.send_splits, group=self.group)
+                    ghost.copy_(recv)
+                else:
+                    dist.all_to_all_single(ghost, buf, output_split_sizes=self.recv_splits,
+                                           input_split_sizes=self.send_splits, group=self.group)
             sent += buf.numel() * buf.element_size()
         self.bytes_sent_per_step = sent
 
@@ -246,7 +254,13 @@ def bench_main(args, rank, world, local_rank):
     from bench import HBM_COPY_GBS, HBM_PEAK_GBS, alg_bytes_per_particle, make_workload
 
     dev = "cuda:%d" % local_rank
-    dist.init_process_group(backend="nccl", device_id=torch.device(dev))
+    # AZP_DIST_BACKEND=gloo rehearses the multi-rank launch on a box with fewer GPUs
+    # than ranks (ghost rows staged through host memory); the product path is RCCL
+    backend = os.environ.get("AZP_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group(backend="nccl", device_id=torch.device(dev))
+    else:
+        dist.init_process_group(backend=backend)
     weak = getattr(args, "scaling", "weak") == "weak" and args.workload == "ns"
     if weak:
         grid = choose_grid(world, np.ones(3))
@@ -318,10 +332,11 @@ def bench_main(args, rank, world, local_rank):
     ev1.record()
     torch.cuda.synchronize()
     kernel_ms = ev0.elapsed_time(ev1) / 10
-    t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    cdev = dev if backend == "nccl" else "cpu"  # device of the small result collectives
+    t = torch.tensor([wall], dtype=torch.float64, device=cdev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
-    counts = torch.tensor([dom.N_local, dom.n_ghost, n_int], dtype=torch.int64, device=dev)
+    counts = torch.tensor([dom.N_local, dom.n_ghost, n_int], dtype=torch.int64, device=cdev)
     gathered = [torch.zeros_like(counts) for _ in range(world)]
     dist.all_gather(gathered, counts)
 
