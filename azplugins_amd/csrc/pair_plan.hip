@@ -622,8 +622,10 @@ static int plan_build_tpp(PairPlan& p, const azp_pair_args& args, uint32_t tpp, 
         }
     p.stage_stride_hint = p.max_stage + p.max_stage / 4 + 64;
     p.total_stage = (uint64_t)p.n_tiles * stride;
-    // 1664 slots x 24 B is the most that still lets four workgroups share a CU's 160 KiB of LDS
-    p.cap = p.max_stage + 1 <= 1024 ? 1024 : (p.max_stage + 1 <= 1536 ? 1536 : (p.max_stage + 1 <= 1664 ? 1664 : (p.max_stage + 1 <= 2048 ? 2048 : 2560)));
+    p.cap = plan_cap_for(p.max_stage);
+    p.h_tile_nstage.resize(p.n_tiles);
+    AZP_HIP_TRY(hipMemcpyAsync(p.h_tile_nstage.data(), p.d_tile_nstage, sizeof(uint32_t) * p.n_tiles, hipMemcpyDeviceToHost, s));
+    AZP_HIP_TRY(hipStreamSynchronize(s));
     p.valid = true;
     return AZP_SUCCESS;
     }

@@ -21,6 +21,7 @@
 // The plan is rebuilt whenever the neighbor list is rebuilt (every ~10-20 MD
 // steps) and reused by every force call in between.
 #pragma once
+#include <vector>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -65,6 +66,16 @@ struct PairPlan
     size_t cap_tiles = 0, cap_slices = 0, cap_stage = 0, cap_cnl = 0;
     uint64_t builds = 0;
     uint32_t stage_stride_hint = 0; // stage_idx entries to reserve per tile next time (last max + 25 %)
+    // host copy of d_tile_nstage: a launch over a sub-range of tiles (domain-decomposed
+    // runs: interior | boundary) picks the LDS variant from the tiles it covers
+    std::vector<uint32_t> h_tile_nstage;
     };
+
+inline uint32_t plan_cap_for(uint32_t max_stage)
+    {
+    // 1664 slots x 24 B is the most that still lets four workgroups share a CU's 160 KiB of LDS
+    const uint32_t need = max_stage + 1;
+    return need <= 1024 ? 1024 : (need <= 1536 ? 1536 : (need <= 1664 ? 1664 : (need <= 2048 ? 2048 : 2560)));
+    }
 
 } // namespace azp

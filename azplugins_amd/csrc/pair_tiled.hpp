@@ -520,7 +520,19 @@ int launch_tiled_instance(const PairPlan& plan, const azp_pair_args& args, const
 template<class E, int TPP, bool VIRIAL, bool SINGLE>
 int launch_tiled_cap(const PairPlan& plan, const azp_pair_args& args, const typename E::Params* d_params, hipStream_t s)
     {
-    switch (plan.cap)
+    // LDS variant: from the tiles this launch covers (all of them unless a range is given)
+    uint32_t cap = plan.cap;
+    if (args.range_count != 0 && !plan.h_tile_nstage.empty())
+        {
+        const uint32_t tb = plan.tile;
+        const uint32_t end = (args.range_first + args.range_count < args.N) ? args.range_first + args.range_count : args.N;
+        const uint32_t t0 = args.range_first / tb, t1 = (end + tb - 1) / tb;
+        uint32_t most = 0;
+        for (uint32_t t = t0; t < t1 && t < plan.n_tiles; ++t)
+            most = plan.h_tile_nstage[t] > most ? plan.h_tile_nstage[t] : most;
+        cap = plan_cap_for(most);
+        }
+    switch (cap)
         {
     case 1024: return launch_tiled_instance<E, TPP, 1024, VIRIAL, SINGLE>(plan, args, d_params, s);
     case 1536: return launch_tiled_instance<E, TPP, 1536, VIRIAL, SINGLE>(plan, args, d_params, s);
