@@ -112,6 +112,7 @@ def run(name, cfg, quick):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", default="", help="comma-separated config names (e.g. C4,C5)")
     args = ap.parse_args()
     cfgs = [("C1", syn.config_c1()), ("C2", syn.config_plj_sc(64)), ("NS", syn.config_north_star(64)),
             ("C3", syn.config_chains()), ("C4", syn.config_dpd()), ("C5", syn.config_tpm())]
@@ -119,6 +120,8 @@ def main():
         cfgs = [("C1", syn.config_c1()), ("C2-24", syn.config_plj_sc(24)), ("C3-small", syn.config_chains(32, 16, 16, 16)),
                 ("C4-small", syn.config_dpd(32768)), ("C5-small", syn.config_tpm(16, 16, 16))]
     rows = []
+    if args.only:
+        cfgs = [c for c in cfgs if c[0] in args.only.split(",")]
     for name, cfg in cfgs:
         rows += run(name, cfg, args.quick)
         print("done", name, file=sys.stderr, flush=True)
