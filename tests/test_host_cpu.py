@@ -150,6 +150,41 @@ def test_type_parameter_validation():
     assert q.params["A-A"]["delta"] == 0.0  # default (src/bond.py:153)
 
 
+def test_external_barrier_host_logic(oracle):
+    """hoomd.azplugins.external mirror: parameter dict semantics of the reference's
+    test_create (src/pytest/test_external.py:36-92), location variants, class names,
+    and the evaluators' validity rules through the C ABI (host functions, no GPU)."""
+    import ctypes as C
+
+    for cls, name in ((azp.external.PlanarHarmonicBarrier, "PlanarHarmonicBarrier"),
+                      (azp.external.SphericalHarmonicBarrier, "SphericalHarmonicBarrier")):
+        b = cls(location=3.0)
+        assert b._cpp_class_name == name
+        b.params["A"].update(dict(k=10.0, offset=0.5))
+        assert b.params["A"] == dict(k=10.0, offset=0.5)
+        b.params["A"]["k"] = 20
+        assert b.params["A"] == dict(k=20.0, offset=0.5)
+        with pytest.raises(ValueError):
+            b.params["B"] = dict(k=1.0)
+        with pytest.raises(ValueError):
+            b.params["B"] = dict(k=1.0, offset=0.0, extra=1.0)
+        assert b._location_at(0) == 3.0
+        b.location = lambda timestep: 5.0 if timestep <= 1 else 4.0
+        assert b._location_at(1) == 5.0 and b._location_at(2) == 4.0
+        with pytest.raises(azp.AzpError):
+            b.forces  # not attached
+    l = _lib.lib()
+    box = _lib.make_box((20.0, 20.0, 20.0))
+    # planar: -L/2 <= H < L/2 (src/PlanarBarrierEvaluator.h:50-58); spherical: 0 <= R and 2R <= min L
+    assert l.azp_planar_barrier_valid(9.9, C.byref(box)) == 1
+    assert l.azp_planar_barrier_valid(10.0, C.byref(box)) == 0
+    assert l.azp_planar_barrier_valid(-10.0, C.byref(box)) == 1
+    assert l.azp_planar_barrier_valid(-10.1, C.byref(box)) == 0
+    assert l.azp_spherical_barrier_valid(10.0, C.byref(box)) == 1
+    assert l.azp_spherical_barrier_valid(10.1, C.byref(box)) == 0
+    assert l.azp_spherical_barrier_valid(-0.1, C.byref(box)) == 0
+
+
 def test_cpp_class_names_match_reference_module():
     """The names the reference registers in _azplugins (src/module.cc:114-164 via
     the export_*.cc.inc templates)."""
