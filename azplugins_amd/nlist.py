@@ -60,6 +60,8 @@ class Cell(NeighborList):
         protocol: fixed-capacity rows, rebuilt when a row overflows);
         ``compact=True`` forces exact rows."""
         self._compact = compact
+        if getattr(state, "order_generation", 0) != getattr(self, "_order_generation", 0):
+            force = True  # the particles were re-indexed (ParticleSorter): every stored index is stale
         if not force and self.nlist is not None:
             if self._built_generation == state.position_generation:
                 return
@@ -176,5 +178,6 @@ class Cell(NeighborList):
 
         self.n_neigh, self.head_list, self.nlist, self.size = n_neigh, head, nlist, size
         self._pos_at_build = state.pos[:n_total].clone()
+        self._order_generation = getattr(state, "order_generation", 0)
         self.num_builds += 1
         self._keep = (rlistsq, cell_of, cell_sorted, order, cell_start, keep)

@@ -32,6 +32,7 @@ class Integrator:
 class _Operations:
     def __init__(self):
         self.integrator = None
+        self.tuners = []  # e.g. azplugins_amd.sorter.ParticleSorter (HOOMD: sim.operations.tuners)
 
 
 class Simulation:
@@ -114,6 +115,12 @@ class Simulation:
             _lib.check(lib.azp_integrate_nve_step_one(C.byref(a), stream), "azp_integrate_nve_step_one")
             st.position_generation += 1
             self.timestep += 1
+            # re-index the particles between the position update and the force
+            # evaluation: every per-particle array that survives the step is permuted,
+            # the forces are recomputed in the new order
+            for tuner in self.operations.tuners:
+                if tuner.trigger_period > 0 and self.timestep % tuner.trigger_period == 0:
+                    tuner.sort(self)
             self._compute_forces()
             a.d_net_force = st.net_force.data_ptr()
             _lib.check(lib.azp_integrate_nve_step_two(C.byref(a), stream), "azp_integrate_nve_step_two")

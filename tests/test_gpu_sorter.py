@@ -1,0 +1,93 @@
+"""ParticleSorter (row N1, "+ particle SFC sort"): a shuffled system cannot be tiled
+(the planned entry point falls back to the generic kernel); after sorting it can,
+and forces / energies are the same per TAG. Bonds are re-indexed."""
+
+import numpy as np
+import pytest
+
+import azplugins_amd as azp
+from azplugins_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _by_tag(sim, force):
+    tag = sim.state.tag.cpu().numpy().view(np.uint32)[: sim.state.N]
+    out = np.zeros((sim.state.N, 4))
+    out[tag] = np.c_[force.forces, force.energies]
+    return out
+
+
+def test_sorter_restores_tiling_and_keeps_forces(oracle):
+    cfg = syn.config_chains(32, 32, 16, 16)
+    n = cfg["xyz"].shape[0]
+    perm = np.argsort(syn.u01(41, np.arange(n, dtype=np.uint64), 0))  # deterministic shuffle
+    inv = np.empty(n, dtype=np.int64)
+    inv[perm] = np.arange(n)
+    xyz = cfg["xyz"][perm]
+    bonds = inv[np.asarray(cfg["bonds"], dtype=np.int64)]
+    snap = azp.Snapshot.from_arrays(xyz, cfg["L"], bonds=bonds, bond_types=("A-A",))
+    sim = azp.Simulation(device="cuda:0", seed=1)
+    sim.create_state_from_snapshot(snap)
+    nl = azp.nlist.Cell(buffer=0.4)
+    plj = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=3.0, mode="shift")
+    plj.params[("A", "A")] = cfg["params"]
+    dw = azp.bond.DoubleWell()
+    dw.params["A-A"] = cfg["bond_params"]
+    sim.operations.integrator = azp.Integrator(dt=0.001, forces=[plj, dw])
+    sim.run(0)
+    assert plj.plan_info["valid"] == 0  # random order: a tile would have to stage far too many particles
+    f_pair0, f_bond0 = _by_tag(sim, plj), _by_tag(sim, dw)
+
+    sorter = azp.ParticleSorter(trigger_period=0)
+    order = sorter.sort(sim).cpu().numpy()
+    assert sorted(order.tolist()) == list(range(n))
+    sim.run(0)
+    assert plj.plan_info["valid"] == 1 and nl.num_builds == 2
+    f_pair1, f_bond1 = _by_tag(sim, plj), _by_tag(sim, dw)
+    scale = np.abs(f_pair0).max()
+    assert np.abs(f_pair1 - f_pair0).max() <= 1e-10 * scale
+    assert np.abs(f_bond1 - f_bond0).max() <= 1e-12 * max(np.abs(f_bond0).max(), 1.0)
+    # and against the oracle on the original (unshuffled) arrays; tags of the shuffled snapshot are 0..n-1 in
+    # shuffled order, so map back through perm
+    pos = syn.pos4(cfg["xyz"])
+    box = oracle.make_box(cfg["L"])
+    excl_n = np.zeros(n, dtype=np.uint32)
+    excl = np.zeros((n, 2), dtype=np.uint32)
+    for a_, b_ in np.asarray(cfg["bonds"], dtype=np.int64):
+        for me, other in ((a_, b_), (b_, a_)):
+            excl[me, excl_n[me]] = other
+            excl_n[me] += 1
+    o_nl = oracle.build_nlist(pos, box, 3.4, exclusions=(excl_n, excl))
+    ref = oracle.pair_forces("PerturbedLennardJones", pos, box, o_nl,
+                             oracle.pack_pair_params("PerturbedLennardJones", cfg["params"]), 3.0, mode="shift")
+    got = np.zeros_like(ref)
+    got[perm] = f_pair1  # tag t of the shuffled snapshot is original particle perm[t]
+    assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max()
+
+
+def test_sorter_in_run_loop_keeps_trajectory():
+    """Sorting every 5 steps during an NVE run changes nothing per tag."""
+    cfg = syn.config_plj_sc(12)
+    n = cfg["xyz"].shape[0]
+    tag = np.arange(n, dtype=np.uint64)
+    vel = np.stack([syn.normal(9, tag, c) for c in range(3)], axis=1) * 0.7
+    vel -= vel.mean(axis=0)
+    out = []
+    for period in (0, 5):
+        sim = azp.Simulation(device="cuda:0", seed=1)
+        sim.create_state_from_snapshot(azp.Snapshot.from_arrays(cfg["xyz"], cfg["L"], velocity=vel))
+        nl = azp.nlist.Cell(buffer=0.4)
+        pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=2.5, mode="shift")
+        pot.params[("A", "A")] = cfg["params"]
+        sim.operations.integrator = azp.Integrator(dt=0.002, forces=[pot], methods=[azp.ConstantVolume()])
+        if period:
+            sim.operations.tuners.append(azp.ParticleSorter(trigger_period=period, particles_per_block=64))
+        sim.run(20)
+        t = sim.state.tag.cpu().numpy().view(np.uint32)
+        x = np.zeros((n, 3))
+        x[t] = sim.state.pos[:, :3].cpu().numpy()
+        out.append(x)
+        if period:
+            assert sim.operations.tuners[0].num_sorts == 4
+    assert np.abs(out[0] - out[1]).max() < 1e-10
