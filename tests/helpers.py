@@ -84,11 +84,14 @@ def _finish(t, virial):
 
 
 def gpu_pair_forces(name, pos, box, nl, params, r_cut, r_on=0.0, mode="none", ntypes=1, N=None, virial=False, tpp=0,
-                    block_size=0, r_list_max=0.0, planned=False, plan_info=None):
+                    block_size=0, r_list_max=0.0, planned=False, plan_info=None, r_inner=None):
     """planned=True: build a tile plan from the list and use the *_planned entry
     point; plan_info (a dict) receives azp_pair_plan_query's answer."""
     a, t = gpu_pair_args(pos, box, nl, ntypes, r_cut, r_on, mode, virial, N, tpp, block_size, r_list_max)
     p = _dev(np.atleast_2d(params).astype(np.float64))
+    if r_inner is not None:  # plan row-ordering hint (azp_pair_args.d_rinnersq)
+        ri = _dev(np.broadcast_to(np.asarray(r_inner, dtype=np.float64) ** 2, (ntypes, ntypes)).reshape(-1).copy())
+        a.d_rinnersq = ri.data_ptr()
     if planned:
         plan = _lib.PairPlan()
         plan.build(a, _stream())

@@ -603,6 +603,45 @@ def test_product_nlist_matches_oracle(oracle):
     assert_close(np.c_[pot.forces, pot.energies], f_ref)
 
 
+@pytest.mark.parametrize("mode", ["none", "shift"])
+@pytest.mark.parametrize("case", ["lam0", "eps0", "rcut_inside_core", "no_core_pairs", "all_core", "lam1"])
+def test_planned_plj_special_cases(oracle, case, mode):
+    """The single-type PerturbedLJ fast path (counted energy offsets, tail-only form,
+    core-first rows): purely repulsive (lambda = 0), epsilon = 0, a cutoff inside the
+    WCA core, no pair / every pair inside the core, lambda = 1 (plain LJ)."""
+    pos, L, _ = H.lattice_config(16, 1.1, 0.11, seed=77, ntypes=1)
+    box = oracle.make_box(L)
+    d = dict(epsilon=1.3, sigma=1.0, attraction_scale_factor=0.5)
+    r_cut = 2.5
+    if case == "lam0":
+        d["attraction_scale_factor"] = 0.0
+    elif case == "lam1":
+        d["attraction_scale_factor"] = 1.0
+    elif case == "eps0":
+        d["epsilon"] = 0.0
+    elif case == "rcut_inside_core":
+        d["sigma"], r_cut = 1.3, 1.4       # r_wca = 1.459 > r_cut
+    elif case == "no_core_pairs":
+        d["sigma"] = 0.7                   # r_wca = 0.786 < every separation
+    elif case == "all_core":
+        d["sigma"], r_cut = 2.4, 2.6       # r_wca = 2.69 > r_cut: every listed in-range pair is in the core
+    params = oracle.pack_pair_params("PerturbedLennardJones", d)
+    nl = oracle.build_nlist(pos, box, r_cut + 0.3)
+    f_ref, v_ref = oracle.pair_forces("PerturbedLennardJones", pos, box, nl, params, r_cut, 0.0, mode, virial=True)
+    r_wca = 2.0 ** (1.0 / 6.0) * d["sigma"]
+    for r_inner in (None, r_wca + 0.3):
+        for virial in (False, True):
+            info = {}
+            out = H.gpu_pair_forces("PerturbedLennardJones", pos, (L,), nl, params, r_cut, 0.0, mode, virial=virial, planned=True,
+                                    plan_info=info, r_list_max=r_cut + 0.3, r_inner=r_inner)
+            f_gpu = out[0] if virial else out
+            assert info["valid"] == 1
+            assert_close(f_gpu[:, :3], f_ref[:, :3], what="force")
+            assert_close(f_gpu[:, 3], f_ref[:, 3], what="energy")
+            if virial:
+                assert_close(out[1], v_ref, what="virial")
+
+
 def test_nlist_single_pass_rebuild_and_overflow(oracle):
     """Rebuilds use fixed-capacity rows and the fill alone; the listed pairs and the
     forces are the same as with exact rows, and a row overflow falls back to exact rows."""
