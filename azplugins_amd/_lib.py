@@ -48,6 +48,9 @@ class PairArgs(C.Structure):
         ("range_count", C.c_uint32),
         ("r_list_max", C.c_double),
         ("d_rinnersq", C.c_void_p),
+        ("has_displacement_bound", C.c_uint32),
+        ("_pad3", C.c_uint32),
+        ("displacement_bound", C.c_double),
     ]
 
 
@@ -201,7 +204,7 @@ SYMBOLS = {
     "azp_nlist_cell_bounds": (C.c_int, [C.POINTER(NlistArgs), _VP]),
     "azp_nlist_count": (C.c_int, [C.POINTER(NlistArgs), _VP]),
     "azp_nlist_fill": (C.c_int, [C.POINTER(NlistArgs), _VP]),
-    "azp_nlist_distance_check": (C.c_int, [C.c_uint32, _VP, _VP, C.POINTER(Box), _D, _VP, _VP]),
+    "azp_nlist_distance_check": (C.c_int, [C.c_uint32, _VP, _VP, C.POINTER(Box), _D, _VP, _VP, _VP]),
     "azp_external_planar_harmonic_barrier": (C.c_int, [C.POINTER(BarrierArgs), _VP]),
     "azp_external_spherical_harmonic_barrier": (C.c_int, [C.POINTER(BarrierArgs), _VP]),
     "azp_planar_barrier_valid": (C.c_int, [_D, C.POINTER(Box)]),

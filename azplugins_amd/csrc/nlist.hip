@@ -304,19 +304,32 @@ template<bool FILL, bool MI> __global__ void __launch_bounds__(NL_THREADS) nlist
 
 __global__ void __launch_bounds__(256) distance_check_kernel(uint32_t n, const double* __restrict__ pos,
                                                              const double* __restrict__ pos0, BoxDev box, double max_dist_sq,
-                                                             uint32_t* __restrict__ flag)
+                                                             uint32_t* __restrict__ flag, unsigned long long* __restrict__ max_bits)
     {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool moved = false;
-    if (i < n)
+    // grid-stride: a few thousand waves, each ending in at most one atomic
+    double dsq_max = 0.0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         {
         const double3 p = load_scalar3_of4(pos, i), q = load_scalar3_of4(pos0, i);
         double dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
         min_image(box, dx, dy, dz);
-        moved = dx * dx + dy * dy + dz * dz > max_dist_sq;
+        dsq_max = fmax(dsq_max, dx * dx + dy * dy + dz * dz);
         }
-    if (__any(moved) && (threadIdx.x & 63) == 0)
-        atomicOr(flag, 1u);
+    for (int off = 32; off > 0; off >>= 1)
+        dsq_max = fmax(dsq_max, __shfl_xor(dsq_max, off, 64));
+    if ((threadIdx.x & 63) == 0)
+        {
+        if (dsq_max > max_dist_sq)
+            atomicOr(flag, 1u);
+        if (max_bits && dsq_max > 0.0)
+            {
+            // the bits of non-negative doubles order like the values; a plain read first
+            // keeps most waves off the atomic
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(dsq_max);
+            if (bits > *reinterpret_cast<volatile unsigned long long*>(max_bits))
+                atomicMax(max_bits, bits);
+            }
+        }
     }
 
 static int check_nlist_args(const azp_nlist_args* a)
@@ -416,14 +429,16 @@ extern "C" int azp_nlist_count(const azp_nlist_args* args, void* stream) { retur
 extern "C" int azp_nlist_fill(const azp_nlist_args* args, void* stream) { return nlist_scan(args, stream, true); }
 
 extern "C" int azp_nlist_distance_check(uint32_t n, const double* d_pos, const double* d_pos_at_build, const azp_box* box,
-                                        double max_dist_sq, uint32_t* d_flag, void* stream)
+                                        double max_dist_sq, uint32_t* d_flag, unsigned long long* d_max_dist_sq_bits,
+                                        void* stream)
     {
     using namespace azp;
     if (!d_pos || !d_pos_at_build || !box || !d_flag || !(max_dist_sq >= 0.0))
         return AZP_ERROR_INVALID_ARGUMENT;
     if (n == 0)
         return AZP_SUCCESS;
-    hipLaunchKernelGGL(distance_check_kernel, dim3((n + 255u) / 256u), dim3(256), 0, static_cast<hipStream_t>(stream), n, d_pos,
-                       d_pos_at_build, make_box_dev(*box), max_dist_sq, d_flag);
+    const uint32_t blocks = (n + 255u) / 256u;
+    hipLaunchKernelGGL(distance_check_kernel, dim3(blocks < 1024u ? blocks : 1024u), dim3(256), 0, static_cast<hipStream_t>(stream), n, d_pos,
+                       d_pos_at_build, make_box_dev(*box), max_dist_sq, d_flag, d_max_dist_sq_bits);
     return (int)hipGetLastError();
     }

@@ -29,6 +29,8 @@ struct PlanKArgs
     const uint64_t* head_list;
     const double* rcutsq;
     const double* rinnersq; // optional (may be null): "core" class radius^2 per type pair
+    uint32_t* slice_Kskip;  // 2 per slice, zeroed before the build kernel
+    double r_list_max;      // caller's hint (r_cut_max + 2 r_buff), 0 = unknown: no shell B
     uint32_t* tile_nstage;
     uint64_t* tile_head;
     uint32_t* stage_idx;
@@ -129,10 +131,11 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
     // (x, y, z, type): they only feed the near/far ordering hint, never a force
     float4* s_p = reinterpret_cast<float4*>(list);
     __shared__ uint32_t s_n, s_overflow;
+    __shared__ float s_far_margin;
     __shared__ float s_rcutsq[64], s_rinnersq[64]; // up to 8 types cached; more types read the global tables
     // bank-aware row ordering (TPP == 1): per wave 32 (part, bank) counters, 2 misfit
     // counters and the list of unclaimed positions
-    __shared__ uint32_t s_bank_cnt[PLAN_BUILD_WAVES][52];
+    __shared__ uint32_t s_bank_cnt[PLAN_BUILD_WAVES][68];
     __shared__ uint16_t s_holes[PLAN_BUILD_WAVES][PLAN_ROWBUF];
 
     const uint32_t tid = threadIdx.x;
@@ -146,7 +149,19 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
         table[t] = PLAN_EMPTY;
     for (uint32_t t = tid; t < 4096; t += NT)
         list[t] = PLAN_EMPTY;
-    if (tid == 0) { s_n = 0; s_overflow = 0; }
+    if (tid == 0)
+        {
+        s_n = 0; s_overflow = 0;
+        // buffer shell B = the outer half of the Verlet buffer: r >= r_cut + r_buff / 2 with
+        // r_buff = (r_list_max - r_cut_max) / 2; published to the host through flags[3]
+        double rc_max_sq = 0.0;
+        for (uint32_t t = 0; t < a.ntypes * a.ntypes; ++t)
+            rc_max_sq = fmax(rc_max_sq, a.rcutsq[t]);
+        const double m = (a.r_list_max > 0.0) ? 0.25 * (a.r_list_max - sqrt(rc_max_sq)) : 0.0;
+        s_far_margin = (m > 0.0) ? (float)m : 0.f;
+        if (blockIdx.x == 0)
+            a.flags[3] = (uint32_t)__float_as_int(s_far_margin);
+        }
     if (rc_cached && tid < a.ntypes * a.ntypes)
         {
         s_rcutsq[tid] = (float)a.rcutsq[tid];
@@ -315,8 +330,13 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
         const uint32_t iters = (n + 63u) >> 6;
         // pass A: translate + classify. Classes: 0 core (inside the evaluator's inner
         // radius hint, e.g. the WCA core of PerturbedLJ), 1 near (inside the cutoff
-        // now), 2 far (only in the Verlet buffer). Rows are written core | near | far.
-        uint32_t n_core = 0, n_near = 0;
+        // now), 2 buffer shell A (r_cut <= r < r_cut + far_margin), 3 buffer shell B
+        // (beyond). Rows are written core | near | A | B. The core / near split is an
+        // ordering hint; the near / A / B split lets the force kernel stop early when
+        // the caller bounds the displacement since this build, so it must be
+        // CONSERVATIVE: the single-precision separation (relative error < 1e-5) has to
+        // clear the boundary by a factor 1 + 1e-4 before an entry counts as outside it.
+        uint32_t n_core = 0, n_near = 0, n_fa = 0;
         uint32_t enc[ITERS]; // (offset << 2) | class, 0 = no entry
 #pragma unroll
         for (int it = 0; it < ITERS; ++it)
@@ -324,7 +344,7 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
             enc[it] = 0;
             if ((uint32_t)it < iters)
                 {
-                bool near = false, core = false;
+                bool near = false, core = false, fa = false;
                 if (jj[it] != PLAN_EMPTY)
                     {
                     const uint32_t sidx = slot_of[plan_find<HC>(table, jj[it])];
@@ -344,16 +364,30 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
                         }
                     const float rsq = dx * dx + dy * dy + dz * dz;
                     const uint32_t tp = trow + (uint32_t)__float_as_int(q.w);
-                    const bool in = rsq < (rc_cached ? s_rcutsq[tp] : (float)a.rcutsq[tp]);
+                    const float rcsq = rc_cached ? s_rcutsq[tp] : (float)a.rcutsq[tp];
+                    const bool in = !(rsq >= rcsq * 1.0001f); // "inside, or too close to call"
                     core = in && rsq < (rc_cached ? s_rinnersq[tp] : (a.rinnersq ? (float)a.rinnersq[tp] : 0.f));
                     near = in && !core;
-                    enc[it] = (((sidx + 1u) * 8u) << 2) | (core ? 0u : (near ? 1u : 2u));
+                    if (!in)
+                        {
+                        const float rb = sqrtf(fmaxf(rcsq, 0.f)) + s_far_margin;
+                        fa = !(s_far_margin > 0.f) || !(rsq >= rb * rb * 1.0001f);
+                        }
+                    enc[it] = (((sidx + 1u) * 8u) << 2) | (core ? 0u : (near ? 1u : (fa ? 2u : 3u)));
                     }
                 n_core += (uint32_t)__popcll(__ballot(core));
                 n_near += (uint32_t)__popcll(__ballot(near));
+                n_fa += (uint32_t)__popcll(__ballot(fa));
                 }
             }
-        const uint32_t seg[4] = {0u, n_core, n_core + n_near, n};
+        if (lane == 0 && p < count)
+            {
+            // chunks a force-kernel wave must process to cover every in-range entry /
+            // every entry up to the end of shell A, over the rows of its slice
+            atomicMax(&a.slice_Kskip[2 * slice], (n_core + n_near + 8u * TPP - 1u) / (8u * TPP));
+            atomicMax(&a.slice_Kskip[2 * slice + 1], (n_core + n_near + n_fa + 8u * TPP - 1u) / (8u * TPP));
+            }
+        const uint32_t seg[5] = {0u, n_core, n_core + n_near, n_core + n_near + n_fa, n};
         if (TPP == 1 && PLAN_BANK_ORDER)
             {
             // pass B (bank-aware): lane l of the force kernel reads its row entry q at
@@ -368,8 +402,8 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
             // (tools/lds_bench.hip): 10.7 -> 7.4 LDS cycles per wave read.
             uint32_t* cnt = s_bank_cnt[wave];
             uint16_t* holes = s_holes[wave];
-            if (lane < 52)
-                cnt[lane] = 0;
+            for (uint32_t t = lane; t < 68; t += 64)
+                cnt[t] = 0;
             for (uint32_t t = lane; t < row_cap; t += 64)
                 rowbuf[t] = (t < n) ? (uint16_t)0xffffu : (uint16_t)0; // unclaimed | padding
             __builtin_amdgcn_wave_barrier();
@@ -392,7 +426,7 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
                 }
             __builtin_amdgcn_wave_barrier();
             // unclaimed positions, in order (class by class)
-            uint32_t n_holes = 0, holes_c0 = 0, holes_c01 = 0;
+            uint32_t n_holes = 0, holes_c0 = 0, holes_c01 = 0, holes_c012 = 0;
             for (uint32_t t0 = 0; t0 < n; t0 += 64)
                 {
                 const uint32_t t = t0 + lane;
@@ -403,6 +437,7 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
                 n_holes += (uint32_t)__popcll(m);
                 holes_c0 += (uint32_t)__popcll(__ballot(hole && t < seg[1]));
                 holes_c01 += (uint32_t)__popcll(__ballot(hole && t < seg[2]));
+                holes_c012 += (uint32_t)__popcll(__ballot(hole && t < seg[3]));
                 }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -411,7 +446,8 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
                 if (misfit & (1u << it))
                     {
                     const uint32_t cls = enc[it] & 3u;
-                    const uint32_t m = atomicAdd(&cnt[48u + cls], 1u) + (cls == 0 ? 0u : (cls == 1 ? holes_c0 : holes_c01));
+                    const uint32_t m = atomicAdd(&cnt[64u + cls], 1u)
+                                       + (cls == 0 ? 0u : (cls == 1 ? holes_c0 : (cls == 2 ? holes_c01 : holes_c012)));
                     rowbuf[holes[m]] = (uint16_t)(enc[it] >> 2);
                     }
                 }
@@ -419,8 +455,8 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
             }
         else
             {
-            // pass B: stable three-way partition into the row buffer
-            uint32_t base[3] = {seg[0], seg[1], seg[2]};
+            // pass B: stable four-way partition into the row buffer
+            uint32_t base[4] = {seg[0], seg[1], seg[2], seg[3]};
 #pragma unroll
             for (int it = 0; it < ITERS; ++it)
                 {
@@ -430,7 +466,7 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
                     const uint32_t cls = enc[it] & 3u;
                     uint32_t posn = 0;
 #pragma unroll
-                    for (uint32_t cidx = 0; cidx < 3; ++cidx)
+                    for (uint32_t cidx = 0; cidx < 4; ++cidx)
                         {
                         const uint64_t m = __ballot(valid && cls == cidx);
                         if (cls == cidx)
@@ -479,6 +515,7 @@ static void plan_free(PairPlan& p)
     if (p.d_tile_head) (void)hipFree(p.d_tile_head);
     if (p.d_stage_idx) (void)hipFree(p.d_stage_idx);
     if (p.d_slice_K) (void)hipFree(p.d_slice_K);
+    if (p.d_slice_Kskip) (void)hipFree(p.d_slice_Kskip);
     if (p.d_slice_head) (void)hipFree(p.d_slice_head);
     if (p.d_cnl) (void)hipFree(p.d_cnl);
     if (p.d_flags) (void)hipFree(p.d_flags);
@@ -552,6 +589,7 @@ static int plan_build_tpp(PairPlan& p, const azp_pair_args& args, uint32_t tpp, 
     AZP_HIP_TRY(ensure(p.d_tile_nstage, p.cap_tiles, p.n_tiles));
     AZP_HIP_TRY(ensure(p.d_tile_head, cap_heads_t, p.n_tiles));
     AZP_HIP_TRY(ensure(p.d_slice_K, p.cap_slices, p.n_slices));
+    AZP_HIP_TRY(ensure(p.d_slice_Kskip, p.cap_kskip, 2 * (size_t)p.n_slices));
     AZP_HIP_TRY(ensure(p.d_slice_head, cap_heads_s, p.n_slices));
     size_t cap_flags = p.d_flags ? 4 : 0;
     AZP_HIP_TRY(ensure(p.d_flags, cap_flags, 4));
@@ -564,6 +602,10 @@ static int plan_build_tpp(PairPlan& p, const azp_pair_args& args, uint32_t tpp, 
     k.head_list = args.d_head_list;
     k.rcutsq = args.d_rcutsq;
     k.rinnersq = args.d_rinnersq;
+    k.slice_Kskip = p.d_slice_Kskip;
+    // buffer shell B: the outer half of the Verlet buffer (r_buff = (r_list_max - r_cut_max) / 2 is
+    // not known here, so the caller's r_list_max hint and the largest cutoff are used when given)
+    k.r_list_max = args.r_list_max;
     k.tile_nstage = p.d_tile_nstage;
     k.tile_head = p.d_tile_head;
     k.stage_idx = nullptr;
@@ -604,6 +646,7 @@ static int plan_build_tpp(PairPlan& p, const azp_pair_args& args, uint32_t tpp, 
         stride = std::min<uint32_t>((stride + 63u) & ~63u, PLAN_MAX_STAGE + 1);
         AZP_HIP_TRY(ensure(p.d_stage_idx, p.cap_stage, (size_t)p.n_tiles * stride));
         AZP_HIP_TRY(hipMemsetAsync(p.d_flags, 0, 4 * sizeof(uint32_t), s));
+        AZP_HIP_TRY(hipMemsetAsync(p.d_slice_Kskip, 0, 2 * sizeof(uint32_t) * p.n_slices, s));
         k.stage_idx = p.d_stage_idx;
         k.cnl = p.d_cnl;
         k.stage_stride = stride;
@@ -622,6 +665,11 @@ static int plan_build_tpp(PairPlan& p, const azp_pair_args& args, uint32_t tpp, 
         }
     p.stage_stride_hint = p.max_stage + p.max_stage / 4 + 64;
     p.total_stage = (uint64_t)p.n_tiles * stride;
+    {
+    float fm;
+    __builtin_memcpy(&fm, &h_flags[3], sizeof(fm));
+    p.far_margin = fm;
+    }
     p.cap = plan_cap_for(p.max_stage);
     p.h_tile_nstage.resize(p.n_tiles);
     AZP_HIP_TRY(hipMemcpyAsync(p.h_tile_nstage.data(), p.d_tile_nstage, sizeof(uint32_t) * p.n_tiles, hipMemcpyDeviceToHost, s));

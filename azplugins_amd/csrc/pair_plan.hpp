@@ -60,10 +60,12 @@ struct PairPlan
     uint64_t* d_tile_head = nullptr;       // n_tiles
     uint32_t* d_stage_idx = nullptr;       // total_stage
     uint32_t* d_slice_K = nullptr;         // n_slices
+    uint32_t* d_slice_Kskip = nullptr;     // 2 x n_slices: chunks up to the end of the in-range entries / of buffer shell A
+    double far_margin = 0.0;               // m of buffer shell B: entries with r_build >= r_cut + m (0: no shell B)
     uint64_t* d_slice_head = nullptr;      // n_slices (chunk units)
     uint4* d_cnl = nullptr;                // total_chunks * 64
     uint32_t* d_flags = nullptr;           // [1] stage overflow, [2] max staged set
-    size_t cap_tiles = 0, cap_slices = 0, cap_stage = 0, cap_cnl = 0;
+    size_t cap_tiles = 0, cap_slices = 0, cap_stage = 0, cap_cnl = 0, cap_kskip = 0;
     uint64_t builds = 0;
     uint32_t stage_stride_hint = 0; // stage_idx entries to reserve per tile next time (last max + 25 %)
     // host copy of d_tile_nstage: a launch over a sub-range of tiles (domain-decomposed

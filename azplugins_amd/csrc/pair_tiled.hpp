@@ -37,6 +37,8 @@ struct TiledKArgs
     const uint64_t* tile_head;
     const uint32_t* stage_idx;
     const uint32_t* slice_K;
+    const uint32_t* slice_Kskip; // 2 per slice: chunks covering the in-range entries / up to the end of buffer shell A
+    uint32_t skip_level;         // 0 whole rows, 1 stop before buffer shell B, 2 stop before the buffer entries
     const uint64_t* slice_head;
     const uint4* cnl;
     };
@@ -414,7 +416,10 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
 #endif
 
     const uint32_t slice = tile * 4 + wave;
-    const uint32_t K = to_uniform(a.slice_K[slice]); // scalar trip count: the loop counter and the chunk address stay in SGPRs
+    // scalar trip count (the loop counter and the chunk address stay in SGPRs). With a
+    // displacement bound from the caller the row ends early: entries that were at
+    // least 2 x bound outside the cutoff when the plan was built cannot be in range.
+    const uint32_t K = to_uniform(a.skip_level == 0 ? a.slice_K[slice] : a.slice_Kskip[2 * slice + (a.skip_level == 1 ? 1 : 0)]);
     // wave-uniform slice base (SGPRs) + lane: the loads use scalar-base addressing
     const uint64_t slice_head = to_uniform(a.slice_head[slice]);
     const char* __restrict__ slice_base = reinterpret_cast<const char*>(a.cnl + slice_head * 64ull);
@@ -479,6 +484,13 @@ int launch_tiled_instance2(const PairPlan& plan, const azp_pair_args& args, cons
     k.tile_head = plan.d_tile_head;
     k.stage_idx = plan.d_stage_idx;
     k.slice_K = plan.d_slice_K;
+    k.slice_Kskip = plan.d_slice_Kskip;
+    k.skip_level = 0;
+    if (args.has_displacement_bound && args.displacement_bound == 0.0)
+        k.skip_level = 2;
+    else if (args.has_displacement_bound && args.displacement_bound > 0.0 && plan.far_margin > 0.0
+             && 2.0 * args.displacement_bound <= plan.far_margin)
+        k.skip_level = 1;
     k.slice_head = plan.d_slice_head;
     k.cnl = plan.d_cnl;
     // sub-range launches are rounded outwards to whole tiles (a tile computed by

@@ -72,18 +72,30 @@ class Cell(NeighborList):
         self._built_generation = state.position_generation
 
     def _moved_too_far(self, state):
-        """One kernel + a 4-byte readback (HOOMD's distance check)."""
+        """One kernel + an 16-byte readback (HOOMD's distance check); also records the
+        largest displacement since the build (``displacement_bound``)."""
         import torch
 
         if getattr(self, "_flag", None) is None or self._flag.device != state.pos.device:
-            self._flag = torch.zeros(1, dtype=torch.int32, device=state.pos.device)
+            self._flag = torch.zeros(2, dtype=torch.int64, device=state.pos.device)  # [flag, max |dx|^2 bits]
         self._flag.zero_()
         box = state.box.to_c()
         stream = torch.cuda.current_stream(state.device).cuda_stream
         _lib.check(_lib.lib().azp_nlist_distance_check(state.n_max, state.pos.data_ptr(), self._pos_at_build.data_ptr(),
-                                                       C.byref(box), (0.5 * self.buffer) ** 2, self._flag.data_ptr(), stream),
+                                                       C.byref(box), (0.5 * self.buffer) ** 2, self._flag.data_ptr(),
+                                                       self._flag.data_ptr() + 8, stream),
                    "azp_nlist_distance_check")
-        return bool(self._flag.item())
+        flag, bits = self._flag.tolist()
+        self._disp = float(np.sqrt(np.array([bits], dtype=np.int64).view(np.float64)[0]))
+        self._disp_generation = state.position_generation
+        return bool(flag)
+
+    def displacement_bound(self, state):
+        """Largest distance any particle has moved since the list was built, if known
+        for the current positions (else None)."""
+        if getattr(self, "_disp_generation", None) == state.position_generation:
+            return self._disp
+        return None
 
     def _build(self, state):
         import torch
@@ -179,5 +191,6 @@ class Cell(NeighborList):
         self.n_neigh, self.head_list, self.nlist, self.size = n_neigh, head, nlist, size
         self._pos_at_build = state.pos[:n_total].clone()
         self._order_generation = getattr(state, "order_generation", 0)
+        self._disp, self._disp_generation = 0.0, state.position_generation
         self.num_builds += 1
         self._keep = (rlistsq, cell_of, cell_sorted, order, cell_start, keep)

@@ -40,6 +40,7 @@ class Pair(Force):
         self.threads_per_particle = 0   # 0 = library heuristic (HOOMD autotunes this)
         self.block_size = 0
         self.use_plan = True            # LDS-staged tile kernel when the neighbor list can be tiled
+        self.use_displacement_bound = True  # let it stop rows early while particles have barely moved (exact)
         self._plan = None
         self._plan_builds = None
         self._tables = None
@@ -151,6 +152,12 @@ class Pair(Force):
         a.block_size = self.block_size
         a.threads_per_particle = self.threads_per_particle
         a.r_list_max = nl.r_list_max
+        # displacement of any particle since the PLAN was built <= displacement since the list was
+        # built (now) + the same quantity at the time the plan was built (0 in the usual flow)
+        bound = nl.displacement_bound(st) if hasattr(nl, "displacement_bound") else None
+        d0 = getattr(self, "_plan_disp0", None)
+        if bound is not None and d0 is not None and self.use_displacement_bound:
+            a.has_displacement_bound, a.displacement_bound = 1, bound + d0
         rng = getattr(self, "_range", None)
         if rng is not None:
             a.range_first, a.range_count = int(rng[0]), int(rng[1])
@@ -186,6 +193,9 @@ class Pair(Force):
                 self._plan.build(a, stream)
                 a.range_first, a.range_count = first, count
                 self._plan_builds = key
+                self._plan_disp0 = self.nlist.displacement_bound(self._state)
+                # this launch sees exactly the positions the plan was built from
+                a.has_displacement_bound, a.displacement_bound = (1 if self.use_displacement_bound else 0), 0.0
             fn = getattr(_lib.lib(), self._planned_entry)
             _lib.check(fn(self._plan.handle, C.byref(a), self._tables["params"].data_ptr(), stream), self._planned_entry)
             return

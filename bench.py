@@ -137,6 +137,9 @@ def main():
                          "random vector of length <= DISPLACE * r_buff / 2 (0 = the snapshot the list was built for, as "
                          "the metric is defined; 1 = the moment before the next rebuild)")
     ap.add_argument("--sort-rows", action="store_true", help="experiment: sort every neighbor row by index before planning")
+    ap.add_argument("--no-displacement-bound", action="store_true",
+                    help="do not tell the planned kernel how far particles moved since the list was built (it then walks "
+                         "whole rows, Verlet-buffer entries included)")
     args = ap.parse_args()
 
     import torch
@@ -172,6 +175,7 @@ def main():
     pot.threads_per_particle = args.tpp
     pot.block_size = args.block_size
     pot.use_plan = not args.no_plan
+    pot.use_displacement_bound = not args.no_displacement_bound
     sim.operations.integrator = azp.Integrator(dt=0.005, forces=[pot])
     sim.run(0)  # attaches, builds the neighbor list (and the tile plan) on the GPU, first force evaluation
     if args.sort_rows:
@@ -202,6 +206,32 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
     ms_per_step = wall * 1e3 / args.steps
 
+    # the same list part-way through a rebuild cycle (outside the timed region): every particle
+    # displaced by <= 0.5 x r_buff/2, then by <= 0.9 x r_buff/2; and with no displacement information
+    def timed(reps=40):
+        pot.compute(0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            pot.compute(0)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    cycle = {}
+    if args.displace == 0.0 and not args.sort_rows:
+        pot.use_displacement_bound = False
+        cycle["no_displacement_information_ms"] = timed()
+        pot.use_displacement_bound = not args.no_displacement_bound
+        x0 = sim.state.pos.clone()
+        for f in (0.5, 0.9):
+            sim.state.pos.copy_(x0)
+            displace_particles(sim.state, f * 0.5 * cfg["r_buff"], seed=11)
+            cycle["displaced_%.1f_x_half_buffer_ms" % f] = timed()
+        assert nl.num_builds == 1
+        sim.state.pos.copy_(x0)
+        sim.state.position_generation += 1
+
     value = N * args.steps / wall
     b_alg = alg_bytes_per_particle(mean_neigh)
     achieved = b_alg * N / (kernel_ms * 1e-3) / 1e9
@@ -230,6 +260,8 @@ def main():
             "mean_neighbors": mean_neigh,
             "displacement_since_list_build": "every particle moved by <= %.3g (= %.2f x r_buff/2)"
                                              % (args.displace * 0.5 * cfg["r_buff"], args.displace),
+            "displacement_bound_passed": bool(pot.use_displacement_bound),
+            "kernel_ms_elsewhere_in_a_rebuild_cycle": cycle,
             "launch": launch,
             "tile_plan": pot.plan_info,
             "parallelism": "1 GPU",

@@ -146,6 +146,23 @@ typedef struct azp_pair_args
                                     an evaluator's short-range branch (PerturbedLJ: the WCA
                                     core, r < 2^(1/6) sigma) is confined to the first chunks
                                     of a row. Ordering hint only; NULL = none.           */
+    uint32_t has_displacement_bound; /* 0 (default): unknown, whole rows are processed        */
+    uint32_t _pad3;
+    double displacement_bound;   /* when has_displacement_bound != 0, read by the *_planned
+                                    entry points: an upper bound on the distance ANY particle
+                                    (local or ghost) has moved since azp_pair_plan_build. Rows
+                                    end with the Verlet-buffer entries, split by their
+                                    separation r_b at build time; an entry with
+                                    r_b >= r_cut + m cannot be in range while
+                                    2 * displacement_bound <= m, so the kernel stops before
+                                    them (exact, not a heuristic):
+                                      bound == 0 (positions unchanged): every buffer entry
+                                            is skipped;
+                                      2 * bound <= r_buff / 2: the outer half of the buffer
+                                            shell is skipped (needs r_list_max at plan build);
+                                      larger: whole rows.
+                                    HOOMD: max |x - x_at_last_nlist_update|, the quantity
+                                    NeighborList::distanceCheck compares with r_buff / 2.    */
     } azp_pair_args;
 
 int azp_pair_forces_perturbed_lennard_jones(const azp_pair_args* args, const azp_plj_params* d_params, void* stream);
@@ -320,9 +337,13 @@ int azp_nlist_fill(const azp_nlist_args* args, void* stream);
 
 /* Rebuild criterion (HOOMD NeighborList::distanceCheck restated): sets *d_flag to 1
  * when any of the n particles moved farther than sqrt(max_dist_sq) from its position
- * at the last build (minimum image in `box`); the caller zeroes *d_flag beforehand. */
+ * at the last build (minimum image in `box`); the caller zeroes *d_flag beforehand.
+ * d_max_dist_sq_bits (optional, may be NULL; zeroed by the caller): receives the bit
+ * pattern of the largest squared displacement as a double (atomic max on the bits,
+ * which order like the values for non-negative doubles) -- the displacement bound the
+ * planned force kernels accept (azp_pair_args.displacement_bound). */
 int azp_nlist_distance_check(uint32_t n, const double* d_pos, const double* d_pos_at_build, const azp_box* box,
-                             double max_dist_sq, uint32_t* d_flag, void* stream);
+                             double max_dist_sq, uint32_t* d_flag, unsigned long long* d_max_dist_sq_bits, void* stream);
 
 /* ---- one-body harmonic barriers ----
  * Replaces the reference's own kernel driver

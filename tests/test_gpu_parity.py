@@ -774,3 +774,43 @@ def test_planned_after_particles_moved(oracle, T):
         torch.cuda.synchronize()
         assert_close(t["force"].cpu().numpy(), f_ref)
     assert crossed >= 1  # some particle was wrapped through the box between build and use
+
+
+@pytest.mark.parametrize("frac", [0.0, 0.2, 0.45, 0.9])
+def test_planned_displacement_bound_is_exact(oracle, frac):
+    """azp_pair_args.displacement_bound: after the plan is built every particle moves
+    by at most frac * r_buff / 2; the planned kernel, told that bound, may stop its rows
+    before buffer entries that cannot have come into range -- the forces must equal the
+    oracle's on the moved positions with the old list. frac = 0: all buffer entries
+    skipped; 0.2, 0.45: the outer half of the buffer shell; 0.9: nothing skipped."""
+    r_cut, r_buff = 2.5, 0.4
+    pos, L, _ = H.lattice_config(16, 1.1, 0.11, seed=91, ntypes=1)
+    box = oracle.make_box(L)
+    params = oracle.pack_pair_params("PerturbedLennardJones", PAIR_PARAMS["PerturbedLennardJones"](0, 0))
+    nl = oracle.build_nlist(pos, box, r_cut + r_buff)
+    n = pos.shape[0]
+    tag = np.arange(n, dtype=np.uint64)
+    v = np.stack([syn.normal(3, tag, c) for c in range(3)], axis=1)
+    amp = frac * 0.5 * r_buff
+    v *= (amp * syn.u01(3, tag, 9) ** (1.0 / 3.0) / np.linalg.norm(v, axis=1))[:, None]
+    # half of the particles sit exactly on the bound
+    v[::2] *= (amp / np.maximum(np.linalg.norm(v[::2], axis=1), 1e-300))[:, None]
+    moved = pos.copy()
+    moved[:, :3] = syn.wrap(pos[:, :3] + v, L)
+    f_ref = oracle.pair_forces("PerturbedLennardJones", moved, box, nl, params, r_cut, 0.0, "shift")
+
+    a, t = H.gpu_pair_args(pos, (L,), nl, 1, r_cut, 0.0, "shift", False, None, 0, 0, r_cut + 2 * r_buff)
+    p = H._dev(np.atleast_2d(params).astype(np.float64))
+    plan = H._lib.PairPlan()
+    plan.build(a, H._stream())                      # built on the ORIGINAL positions
+    assert plan.info()["valid"] == 1
+    import torch
+    t["pos"].copy_(torch.from_numpy(moved))          # then the particles move
+    results = {}
+    for label, known, bound in (("unknown", 0, 0.0), ("bound", 1, amp * (1 + 1e-12))):
+        a.has_displacement_bound, a.displacement_bound = known, bound
+        H._lib.check(H._lib.lib().azp_pair_forces_planned_perturbed_lennard_jones(plan.handle, H.C.byref(a), p.data_ptr(),
+                                                                                 H._stream()), "planned")
+        results[label] = H._finish(t, False)
+    assert_close(results["unknown"], f_ref)
+    assert_close(results["bound"], f_ref)
