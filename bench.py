@@ -137,6 +137,9 @@ def main():
                          "random vector of length <= DISPLACE * r_buff / 2 (0 = the snapshot the list was built for, as "
                          "the metric is defined; 1 = the moment before the next rebuild)")
     ap.add_argument("--sort-rows", action="store_true", help="experiment: sort every neighbor row by index before planning")
+    ap.add_argument("--cycle-report", action="store_true",
+                    help="after the timed region, also time the kernel without displacement information and with every "
+                         "particle displaced by 0.5 / 0.9 x r_buff/2 (same list and plan); reported in config")
     ap.add_argument("--no-displacement-bound", action="store_true",
                     help="do not tell the planned kernel how far particles moved since the list was built (it then walks "
                          "whole rows, Verlet-buffer entries included)")
@@ -219,7 +222,7 @@ def main():
         return e0.elapsed_time(e1) / reps
 
     cycle = {}
-    if args.displace == 0.0 and not args.sort_rows:
+    if args.cycle_report and args.displace == 0.0 and not args.sort_rows:
         pot.use_displacement_bound = False
         cycle["no_displacement_information_ms"] = timed()
         pot.use_displacement_bound = not args.no_displacement_bound
@@ -261,6 +264,9 @@ def main():
             "displacement_since_list_build": "every particle moved by <= %.3g (= %.2f x r_buff/2)"
                                              % (args.displace * 0.5 * cfg["r_buff"], args.displace),
             "displacement_bound_passed": bool(pot.use_displacement_bound),
+            "note": "static list (the metric's definition): the kernel is told that no particle moved since the list was "
+                    "built and stops each row before its Verlet-buffer entries (exact). --cycle-report times the same "
+                    "list mid-cycle; profiles/r01d_cycle.json holds that run.",
             "kernel_ms_elsewhere_in_a_rebuild_cycle": cycle,
             "launch": launch,
             "tile_plan": pot.plan_info,
