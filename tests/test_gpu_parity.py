@@ -814,3 +814,35 @@ def test_planned_displacement_bound_is_exact(oracle, frac):
         results[label] = H._finish(t, False)
     assert_close(results["unknown"], f_ref)
     assert_close(results["bound"], f_ref)
+
+
+def test_north_star_full_size_properties():
+    """N = 1,048,576 (BASELINE.json's headline size), through size-independent
+    properties: total force = 0 (third law, though the kernel uses full lists); the
+    planned kernel agrees with the generic one; stopping rows at the displacement bound
+    changes no bit (skipped pairs are out of range and would have added +0.0)."""
+    import azplugins_amd as azp
+
+    cfg = syn.config_north_star(64)
+    n = cfg["xyz"].shape[0]
+    sim = azp.Simulation(device="cuda:0", seed=1)
+    sim.create_state_from_snapshot(azp.Snapshot.from_arrays(cfg["xyz"], cfg["L"]))
+    nl = azp.nlist.Cell(buffer=cfg["r_buff"])
+    pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=cfg["r_cut"], mode="shift")
+    pot.params[("A", "A")] = cfg["params"]
+    sim.operations.integrator = azp.Integrator(dt=0.005, forces=[pot])
+    sim.run(0)
+    assert pot.plan_info["valid"] == 1 and n == 1048576
+    f_bound = pot.force_tensor.clone()
+    pot.use_displacement_bound = False
+    pot.compute(0)
+    f_whole = pot.force_tensor.clone()
+    assert bool((f_bound == f_whole).all())
+    pot.use_plan = False
+    pot.compute(0)
+    f_generic = pot.force_tensor.clone()
+    scale = float(f_generic[:, :3].abs().max())
+    assert float((f_generic - f_whole).abs().max()) <= 1e-11 * max(scale, float(f_generic[:, 3].abs().max()))
+    total = f_whole[:, :3].sum(dim=0).abs().max()
+    assert float(total) <= 1e-9 * scale
+    assert abs(nl.n_pairs / n - 136.26) < 0.05
