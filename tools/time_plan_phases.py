@@ -1,3 +1,5 @@
+"""Plan-build timing against a library built with -DPLAN_ABLATE=1|2|3 (AZP_LIB_PATH): phase breakdown.
+The product run uses the generic kernel (an ablated library leaves the plan incomplete)."""
 import sys, os, time
 sys.path.insert(0, "/root/repo")
 import torch
