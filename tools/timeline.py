@@ -2,7 +2,8 @@
 -DAZP_TIMELINE, see pair_tiled.hpp): where does the launch lose time -- staging,
 imbalance between the waves of a tile, the tail of the launch?
 
-    AZP_LIB_PATH=tools/abl/libazp_tl.so python tools/timeline.py
+    make -C azplugins_amd/csrc timeline
+    AZP_LIB_PATH=tools/libazp_timeline.so python tools/timeline.py
 """
 import ctypes as C
 import os
