@@ -204,6 +204,7 @@ SYMBOLS = {
     "azp_nlist_cell_bounds": (C.c_int, [C.POINTER(NlistArgs), _VP]),
     "azp_nlist_count": (C.c_int, [C.POINTER(NlistArgs), _VP]),
     "azp_nlist_fill": (C.c_int, [C.POINTER(NlistArgs), _VP]),
+    "azp_halo_pack": (C.c_int, [C.c_uint32, _VP, _VP, C.c_uint32, _VP, _VP]),
     "azp_nlist_distance_check": (C.c_int, [C.c_uint32, _VP, _VP, C.POINTER(Box), _D, _VP, _VP, _VP]),
     "azp_external_planar_harmonic_barrier": (C.c_int, [C.POINTER(BarrierArgs), _VP]),
     "azp_external_spherical_harmonic_barrier": (C.c_int, [C.POINTER(BarrierArgs), _VP]),

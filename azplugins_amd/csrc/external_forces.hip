@@ -230,3 +230,32 @@ extern "C" int azp_spherical_barrier_valid(double R, const azp_box* box)
     const double two_R = 2.0 * R;
     return (R >= 0.0 && dx >= two_R && dy >= two_R && dz >= two_R) ? 1 : 0;
     }
+
+// ---- halo pack: gather rows into the send buffer ----
+namespace azp
+{
+__global__ void __launch_bounds__(256) halo_pack_kernel(uint32_t n, const double* __restrict__ src, const int64_t* __restrict__ idx,
+                                                        uint32_t row_doubles, double* __restrict__ dst)
+    {
+    // one lane per 16 bytes: a 4-double row is two lanes, consecutive lanes write consecutive addresses
+    const uint32_t per_row = row_doubles / 2;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)n * per_row)
+        return;
+    const uint32_t k = (uint32_t)(t / per_row), part = (uint32_t)(t % per_row);
+    const double2 v = *reinterpret_cast<const double2*>(src + (uint64_t)idx[k] * row_doubles + 2 * part);
+    *reinterpret_cast<double2*>(dst + (uint64_t)k * row_doubles + 2 * part) = v;
+    }
+} // namespace azp
+
+extern "C" int azp_halo_pack(uint32_t n, const double* d_src, const int64_t* d_idx, uint32_t row_doubles, double* d_dst, void* stream)
+    {
+    if (!d_src || !d_idx || !d_dst || row_doubles == 0 || (row_doubles & 1u))
+        return AZP_ERROR_INVALID_ARGUMENT;
+    if (n == 0)
+        return AZP_SUCCESS;
+    const uint64_t lanes = (uint64_t)n * (row_doubles / 2);
+    hipLaunchKernelGGL(azp::halo_pack_kernel, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n,
+                       d_src, d_idx, row_doubles, d_dst);
+    return (int)hipGetLastError();
+    }

@@ -101,6 +101,19 @@ class Decomposition:
         return mask
 
 
+def _blocked_key(xyz, lo, extent, density, block=4, particles_per_block=256):
+    """Sort key of a blocked cell curve over the region [lo, lo + extent): cells of
+    width w with block^3 cells holding about particles_per_block particles."""
+    w = (particles_per_block / density) ** (1.0 / 3.0) / block
+    dims = np.maximum(np.ceil(np.asarray(extent, dtype=np.float64) / w).astype(np.int64), 1)
+    c = np.floor((xyz - lo) / w).astype(np.int64)
+    c = np.minimum(np.maximum(c, 0), dims - 1)
+    nb = (dims + block - 1) // block
+    key = ((c[:, 2] // block) * nb[1] + (c[:, 1] // block)) * nb[0] + (c[:, 0] // block)
+    inner = ((c[:, 2] % block) * block + (c[:, 1] % block)) * block + (c[:, 0] % block)
+    return key * block ** 3 + inner
+
+
 class RankDomain:
     """Everything one rank needs: its local particles, its ghosts grouped by
     owning rank, and which of its local particles every peer needs.
@@ -120,8 +133,18 @@ class RankDomain:
         # (global) order is kept inside each group. Forces of the interior group do
         # not depend on the halo, so they overlap with the exchange.
         shell_local = decomp.depth(xyz_global[local], rank) < decomp.r_ghost
-        self.local_gid = np.concatenate([local[~shell_local], local[shell_local]])
-        self.n_interior = int((~shell_local).sum())
+        # inside each group the particles follow a blocked cell curve anchored at the
+        # group's own corner, so that 256 consecutive particles are a compact tile again
+        # (the global curve's blocks are cut by the interior / boundary split)
+        lo, hi = decomp.bounds(rank)
+        lo, hi = np.asarray(lo, dtype=np.float64), np.asarray(hi, dtype=np.float64)
+        density = xyz_global.shape[0] / float(np.prod(decomp.L))
+        interior, boundary = local[~shell_local], local[shell_local]
+        lo_int = lo + np.where(np.asarray(decomp.grid) > 1, decomp.r_ghost, 0.0)
+        interior = interior[np.argsort(_blocked_key(xyz_global[interior], lo_int, hi - lo_int, density), kind="stable")]
+        boundary = boundary[np.argsort(_blocked_key(xyz_global[boundary], lo, hi - lo, density), kind="stable")]
+        self.local_gid = np.concatenate([interior, boundary])
+        self.n_interior = int(interior.size)
         shell = decomp.in_ghost_shell(xyz_global, rank)
         ghost_mask = shell & (owner != rank)
         ghost_gid = np.flatnonzero(ghost_mask)
@@ -181,12 +204,20 @@ class HaloExchange:
         """Gather the rows the peers need into the send buffers (current stream)."""
         import torch
 
+        from . import _lib
+
         N = self.domain.N_local
         out = []
         for slot, a in enumerate(arrays):
             a2 = a if a.dim() == 2 else a.unsqueeze(1)
             buf = self._buf(a2, a2.shape[1], slot)
-            torch.index_select(a2[:N], 0, self.send_idx, out=buf)
+            if a2.is_cuda and a2.dtype == torch.float64 and a2.shape[1] % 2 == 0 and a2.is_contiguous():
+                # libazp gather kernel (rows of doubles): ~8x faster than index_select here
+                stream = torch.cuda.current_stream(a2.device).cuda_stream
+                _lib.check(_lib.lib().azp_halo_pack(self.send_idx.numel(), a2.data_ptr(), self.send_idx.data_ptr(), a2.shape[1],
+                                                    buf.data_ptr(), stream), "azp_halo_pack")
+            else:
+                torch.index_select(a2[:N], 0, self.send_idx, out=buf)
             out.append((a2, buf))
         return out
 
@@ -299,16 +330,16 @@ def bench_main(args, rank, world, local_rank):
         overlap = True
 
     def step():
-        packed = halo.pack(state.pos)           # gather the rows the peers need
         if overlap:
             comm.wait_stream(main)
             with torch.cuda.stream(comm):
+                packed = halo.pack(state.pos)   # gather the rows the peers need
                 halo.transfer(packed)           # ghost positions over RCCL/xGMI
-            pot.compute(0, particle_range=(0, n_int))       # needs no ghost
+            pot.compute(0, particle_range=(0, n_int))       # needs no ghost: runs beside pack + exchange
             main.wait_stream(comm)
             pot.compute(0, particle_range=(n_int, n_bnd))   # shell particles
         else:
-            halo.transfer(packed)
+            halo.transfer(halo.pack(state.pos))
             pot.compute(0)
 
     for _ in range(args.warmup):

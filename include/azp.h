@@ -345,6 +345,11 @@ int azp_nlist_fill(const azp_nlist_args* args, void* stream);
 int azp_nlist_distance_check(uint32_t n, const double* d_pos, const double* d_pos_at_build, const azp_box* box,
                              double max_dist_sq, uint32_t* d_flag, unsigned long long* d_max_dist_sq_bits, void* stream);
 
+/* ---- halo pack: dst[k, :] = src[idx[k], :] for k < n, rows of
+ * row_doubles doubles (4 for positions / velocities / orientations). The send buffer of
+ * the per-step ghost exchange; replaces the pack half of HOOMD's CommunicatorGPU. */
+int azp_halo_pack(uint32_t n, const double* d_src, const int64_t* d_idx, uint32_t row_doubles, double* d_dst, void* stream);
+
 /* ---- one-body harmonic barriers ----
  * Replaces the reference's own kernel driver
  *   azplugins::gpu::compute_harmonic_barrier<Evaluator>(...)   (src/HarmonicBarrierGPU.cuh:49-140,
