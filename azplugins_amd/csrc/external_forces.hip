@@ -250,10 +250,10 @@ __global__ void __launch_bounds__(256) halo_pack_kernel(uint32_t n, const double
 
 extern "C" int azp_halo_pack(uint32_t n, const double* d_src, const int64_t* d_idx, uint32_t row_doubles, double* d_dst, void* stream)
     {
+    if (n == 0)
+        return AZP_SUCCESS; // a rank without peers: empty buffers, possibly null
     if (!d_src || !d_idx || !d_dst || row_doubles == 0 || (row_doubles & 1u))
         return AZP_ERROR_INVALID_ARGUMENT;
-    if (n == 0)
-        return AZP_SUCCESS;
     const uint64_t lanes = (uint64_t)n * (row_doubles / 2);
     hipLaunchKernelGGL(azp::halo_pack_kernel, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n,
                        d_src, d_idx, row_doubles, d_dst);

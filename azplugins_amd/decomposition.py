@@ -288,6 +288,13 @@ def bench_main(args, rank, world, local_rank):
     # AZP_DIST_BACKEND=gloo rehearses the multi-rank launch on a box with fewer GPUs
     # than ranks (ghost rows staged through host memory); the product path is RCCL
     backend = os.environ.get("AZP_DIST_BACKEND", "nccl")
+    # RCCL writes its version banner to the process's stdout (fd 1), which has to carry exactly
+    # one JSON line: point fd 1 at stderr until the result is printed
+    import sys
+
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     if backend == "nccl":
         dist.init_process_group(backend="nccl", device_id=torch.device(dev))
     else:
@@ -409,6 +416,11 @@ def bench_main(args, rank, world, local_rank):
                 "kernel_ms": kernel_ms, "algorithmic_bytes_per_particle": b_alg,
             },
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     dist.barrier()
     dist.destroy_process_group()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
