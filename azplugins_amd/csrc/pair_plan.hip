@@ -652,6 +652,8 @@ static int plan_build_tpp(PairPlan& p, const azp_pair_args& args, uint32_t tpp, 
         k.stage_stride = stride;
         AZP_HIP_TRY(launch_plan(tpp, 1, k, p.n_tiles, s));
         AZP_HIP_TRY(hipMemcpyAsync(h_flags, p.d_flags, sizeof(h_flags), hipMemcpyDeviceToHost, s));
+        p.h_tile_nstage.resize(p.n_tiles); // per-tile stage counts ride on the same synchronisation
+        AZP_HIP_TRY(hipMemcpyAsync(p.h_tile_nstage.data(), p.d_tile_nstage, sizeof(uint32_t) * p.n_tiles, hipMemcpyDeviceToHost, s));
         AZP_HIP_TRY(hipStreamSynchronize(s));
         p.max_stage = h_flags[2];
         if (!h_flags[1])
@@ -671,9 +673,6 @@ static int plan_build_tpp(PairPlan& p, const azp_pair_args& args, uint32_t tpp, 
     p.far_margin = fm;
     }
     p.cap = plan_cap_for(p.max_stage);
-    p.h_tile_nstage.resize(p.n_tiles);
-    AZP_HIP_TRY(hipMemcpyAsync(p.h_tile_nstage.data(), p.d_tile_nstage, sizeof(uint32_t) * p.n_tiles, hipMemcpyDeviceToHost, s));
-    AZP_HIP_TRY(hipStreamSynchronize(s));
     p.valid = true;
     return AZP_SUCCESS;
     }
