@@ -8,9 +8,10 @@
 //           set exceeds PLAN_MAX_STAGE particles -- e.g. unsorted particle order --
 //           invalidates the plan); the staged positions are loaded into LDS; every
 //           row entry is translated (hash lookup) to a u16 byte offset, classified
-//           near / far (inside the cutoff now or only in the Verlet buffer), and the
-//           row is written near-first as 16-byte chunks in the force kernel's own
-//           lane order.
+//           core / near / buffer shell A / buffer shell B, placed bank-aware inside
+//           its class, and the row is written as 16-byte chunks in the force
+//           kernel's own lane order; per slice the chunk counts up to the end of the
+//           in-range entries and of shell A are kept for the displacement bound.
 // The host-side scan makes plan build a sync point, like HOOMD's own
 // neighbor-list overflow check.
 #include <algorithm>

@@ -7,9 +7,14 @@
 //      tile's reference particle. Slot 0 is a dummy parked at 1e30 for padding.
 //   2. loop: each lane reads one 16-byte chunk = 8 u16 byte offsets per
 //      iteration (a wave reads 1 KiB contiguous), then for each of the 8
-//      neighbors three ds_read_b64 gathers and the evaluator. No global gathers,
-//      no minimum image, no row-length test (rows are padded with the dummy),
-//      8 independent pairs in flight per lane.
+//      neighbors three LDS gathers and the evaluator, software-pipelined in
+//      batches of 4 pairs. No global gathers, no minimum image, no row-length
+//      test (rows are padded with the dummy). Rows are ordered core | near |
+//      buffer shell A | B (pair_plan.hip): a batch with no pair in range is
+//      skipped after the separations, a batch with no pair in the evaluator's
+//      core uses the cheaper tail form (PerturbedLJ), and the row ends before
+//      the buffer entries when the caller bounds the displacement since the
+//      plan was built (skip_level).
 //   3. DPP butterfly over the TPP lanes, lane 0 stores force (and virial).
 // Same evaluators, same outputs as pair_kernel.hpp; results agree with it to
 // rounding (the periodic shift is applied to r_j instead of to r_i - r_j).
