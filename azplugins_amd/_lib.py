@@ -190,6 +190,7 @@ SYMBOLS = {
     "azp_pair_plan_create": (C.c_int, [C.POINTER(_VP)]),
     "azp_pair_plan_destroy": (None, [_VP]),
     "azp_pair_plan_build": (C.c_int, [_VP, C.POINTER(PairArgs), _VP]),
+    "azp_pair_plan_set_bank_order": (C.c_int, [_VP, C.c_int]),
     "azp_pair_plan_query": (C.c_int, [_VP, C.POINTER(PlanInfo)]),
     "azp_pair_forces_planned_perturbed_lennard_jones": (C.c_int, [_VP, C.POINTER(PairArgs), _VP, _VP]),
     "azp_pair_forces_planned_hertz": (C.c_int, [_VP, C.POINTER(PairArgs), _VP, _VP]),
@@ -271,6 +272,9 @@ class PairPlan:
 
     def build(self, args, stream):
         check(lib().azp_pair_plan_build(self._h, C.byref(args), stream), "azp_pair_plan_build")
+
+    def set_bank_order(self, enabled):
+        check(lib().azp_pair_plan_set_bank_order(self._h, int(bool(enabled))), "azp_pair_plan_set_bank_order")
 
     def info(self):
         i = PlanInfo()

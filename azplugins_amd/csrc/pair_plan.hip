@@ -32,6 +32,7 @@ struct PlanKArgs
     const double* rinnersq; // optional (may be null): "core" class radius^2 per type pair
     uint32_t* slice_Kskip;  // 2 per slice, zeroed before the build kernel
     double r_list_max;      // caller's hint (r_cut_max + 2 r_buff), 0 = unknown: no shell B
+    uint32_t bank_order;    // bank-aware row order (build option)
     uint32_t* tile_nstage;
     uint64_t* tile_head;
     uint32_t* stage_idx;
@@ -389,7 +390,7 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
             atomicMax(&a.slice_Kskip[2 * slice + 1], (n_core + n_near + n_fa + 8u * TPP - 1u) / (8u * TPP));
             }
         const uint32_t seg[5] = {0u, n_core, n_core + n_near, n_core + n_near + n_fa, n};
-        if (TPP == 1 && PLAN_BANK_ORDER)
+        if (TPP == 1 && PLAN_BANK_ORDER && a.bank_order)
             {
             // pass B (bank-aware): lane l of the force kernel reads its row entry q at
             // step q, together with the other 63 rows of the slice. A 64-lane
@@ -607,6 +608,7 @@ static int plan_build_tpp(PairPlan& p, const azp_pair_args& args, uint32_t tpp, 
     // buffer shell B: the outer half of the Verlet buffer (r_buff = (r_list_max - r_cut_max) / 2 is
     // not known here, so the caller's r_list_max hint and the largest cutoff are used when given)
     k.r_list_max = args.r_list_max;
+    k.bank_order = p.bank_order ? 1u : 0u;
     k.tile_nstage = p.d_tile_nstage;
     k.tile_head = p.d_tile_head;
     k.stage_idx = nullptr;
@@ -735,6 +737,14 @@ extern "C" int azp_pair_plan_build(azp_pair_plan* plan, const azp_pair_args* arg
         || args->ntypes == 0)
         return AZP_ERROR_INVALID_ARGUMENT;
     return azp::plan_build(*reinterpret_cast<azp::PairPlan*>(plan), *args, static_cast<hipStream_t>(stream));
+    }
+
+extern "C" int azp_pair_plan_set_bank_order(azp_pair_plan* plan, int enabled)
+    {
+    if (!plan)
+        return AZP_ERROR_INVALID_ARGUMENT;
+    reinterpret_cast<azp::PairPlan*>(plan)->bank_order = enabled != 0;
+    return AZP_SUCCESS;
     }
 
 extern "C" int azp_pair_plan_query(const azp_pair_plan* plan, azp_pair_plan_info* info)

@@ -67,6 +67,7 @@ struct PairPlan
     uint32_t* d_flags = nullptr;           // [1] stage overflow, [2] max staged set
     size_t cap_tiles = 0, cap_slices = 0, cap_stage = 0, cap_cnl = 0, cap_kskip = 0;
     uint64_t builds = 0;
+    bool bank_order = true;         // build option (azp_pair_plan_set_bank_order)
     uint32_t stage_stride_hint = 0; // stage_idx entries to reserve per tile next time (last max + 25 %)
     // host copy of d_tile_nstage: a launch over a sub-range of tiles (domain-decomposed
     // runs: interior | boundary) picks the LDS variant from the tiles it covers

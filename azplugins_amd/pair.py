@@ -190,12 +190,18 @@ class Pair(Force):
                 # recompile the plan only when the neighbor list was rebuilt
                 first, count = a.range_first, a.range_count
                 a.range_first = a.range_count = 0
+                # bank-aware rows pay off only for lists that live long (include/azp.h): keep them
+                # for the first build and whenever the previous list served >= 50 force calls
+                calls = getattr(self, "_calls_since_plan", None)
+                self._plan.set_bank_order(calls is None or calls >= 50)
+                self._calls_since_plan = 0
                 self._plan.build(a, stream)
                 a.range_first, a.range_count = first, count
                 self._plan_builds = key
                 self._plan_disp0 = self.nlist.displacement_bound(self._state)
                 # this launch sees exactly the positions the plan was built from
                 a.has_displacement_bound, a.displacement_bound = (1 if self.use_displacement_bound else 0), 0.0
+            self._calls_since_plan = getattr(self, "_calls_since_plan", 0) + 1
             fn = getattr(_lib.lib(), self._planned_entry)
             _lib.check(fn(self._plan.handle, C.byref(a), self._tables["params"].data_ptr(), stream), self._planned_entry)
             return

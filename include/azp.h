@@ -206,6 +206,10 @@ typedef struct azp_pair_plan_info
 int azp_pair_plan_create(azp_pair_plan** out);
 void azp_pair_plan_destroy(azp_pair_plan* plan);
 int azp_pair_plan_build(azp_pair_plan* plan, const azp_pair_args* args, void* stream);
+/* Build option: order every row bank-aware (conflict-poor LDS gathers; default on).
+ * It adds ~10 % to the build and buys ~2-3 % per force call, so it pays for lists that
+ * live for more than ~50 force calls; callers that rebuild more often turn it off. */
+int azp_pair_plan_set_bank_order(azp_pair_plan* plan, int enabled);
 int azp_pair_plan_query(const azp_pair_plan* plan, azp_pair_plan_info* info);
 
 int azp_pair_forces_planned_perturbed_lennard_jones(azp_pair_plan* plan, const azp_pair_args* args,
