@@ -323,6 +323,12 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
         s_x[0] = PLAN_FAR; s_y[0] = PLAN_FAR; s_z[0] = PLAN_FAR;
         if (!SINGLE) s_t[0] = 0;
         }
+    // this lane's own particle: its load is issued first and consumed after the staging
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63; // wave id: scalar
+    const uint32_t pl = lane / TPP;
+    const uint32_t idx = first + wave * PW + pl;
+    const bool active = idx < a.p.end;
+    const double4 own = load_scalar4(a.p.pos, active ? idx : first);
     // All loads of the staging are issued before the first result is used: the index
     // loads of every round first, then every position load (two dependent HBM round
     // trips per tile instead of two per 256 staged particles -- the staging took 17 of
@@ -382,10 +388,6 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
     }
 
     // ---- this lane's particle, in the same image frame ----
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63; // wave id: scalar
-    const uint32_t pl = lane / TPP;
-    const uint32_t idx = first + wave * PW + pl;
-    const bool active = idx < a.p.end;
     double3 pi = make_double3(0.0, 0.0, 0.0);
     int typei = 0;
     // Fast path condition, per tile: every member is closer to c than L/2 minus
@@ -394,7 +396,7 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
     bool lane_wide = (a.p.r_list_max <= 0.0) || a.p.box.triclinic;
     if (active)
         {
-        const double4 p = load_scalar4(a.p.pos, idx);
+        const double4 p = own;
         double x = p.x, y = p.y, z = p.z;
         if (!a.p.box.triclinic)
             {
