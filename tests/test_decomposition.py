@@ -1,4 +1,4 @@
-"""Domain decomposition + halo exchange on CPU (gloo, world_size 2 and 4) --
+"""Domain decomposition + halo exchange on CPU (gloo, world_size 2, 4 and 8) --
 the N > 1 path of bench.py, with the oracle standing in for the GPU kernels:
 the union of per-rank forces (own particles, own + ghost positions, full lists)
 must equal the single-domain forces."""
@@ -61,6 +61,10 @@ def _free_port():
     return p
 
 
+def _n_side(world):
+    return 12 if world <= 4 else 16  # 2x2x2: keep every sub-box wider than two ghost shells
+
+
 def _worker(rank, world, port, out_dir):
     import torch
     import torch.distributed as dist
@@ -70,7 +74,7 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    cfg = syn.config_plj_sc(12)
+    cfg = syn.config_plj_sc(_n_side(world))
     r_cut, r_buff = 2.5, 0.3
     dec = dd.Decomposition(cfg["L"], world, r_cut + r_buff)
     dom = dd.RankDomain(dec, rank, cfg["xyz"])
@@ -114,13 +118,13 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_halo_exchange_and_forces_gloo(world, tmp_path, oracle):
     import torch.multiprocessing as mp
 
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    cfg = syn.config_plj_sc(12)
+    cfg = syn.config_plj_sc(_n_side(world))
     g = np.arange(cfg["xyz"].shape[0])
     xyz = cfg["xyz"] + 0.05 * np.stack([np.sin(g * 0.37), np.cos(g * 0.11), np.sin(g * 0.23 + 1.0)], axis=1)
     pos = syn.pos4(xyz)
