@@ -382,6 +382,34 @@ def bench_main(args, rank, world, local_rank):
     gathered = [torch.zeros_like(counts) for _ in range(world)]
     dist.all_gather(gathered, counts)
 
+    verify = None
+    if os.environ.get("AZP_BENCH_VERIFY") == "1":
+        # rehearsal check: the decomposed forces against one single-domain evaluation of
+        # the whole system on rank 0's GPU (files under the temp dir, keyed by global id)
+        import tempfile
+
+        tmp = os.path.join(tempfile.gettempdir(), "azp_verify_%s" % os.environ.get("MASTER_PORT", "0"))
+        os.makedirs(tmp, exist_ok=True)
+        pot.compute(0)
+        np.savez(os.path.join(tmp, "rank%d.npz" % rank), gid=dom.local_gid, force=pot.force_tensor.cpu().numpy())
+        dist.barrier()
+        if rank == 0:
+            sim1 = azp.Simulation(device=dev, seed=1)
+            sim1.create_state_from_snapshot(azp.Snapshot.from_arrays(cfg["xyz"], cfg["L"]))
+            nl1 = azp.nlist.Cell(buffer=cfg["r_buff"])
+            pot1 = azp.pair.PerturbedLennardJones(nlist=nl1, default_r_cut=cfg["r_cut"], mode=args.mode)
+            pot1.params[("A", "A")] = cfg["params"]
+            sim1.operations.integrator = azp.Integrator(dt=0.005, forces=[pot1])
+            sim1.run(0)
+            ref = pot1.force_tensor.cpu().numpy()
+            got = np.full_like(ref, np.nan)
+            for r in range(world):
+                d = np.load(os.path.join(tmp, "rank%d.npz" % r))
+                got[d["gid"]] = d["force"]
+            verify = float(np.abs(got - ref).max() / np.abs(ref).max())
+            del sim1, pot1, nl1
+        dist.barrier()
+
     if rank == 0:
         b_alg = alg_bytes_per_particle(mean_neigh)
         achieved = b_alg * dom.N_local / (kernel_ms * 1e-3) / 1e9
@@ -410,6 +438,7 @@ def bench_main(args, rank, world, local_rank):
                 "parallelism": "dd%d" % world,
                 "per_rank": [dict(N_local=int(g[0]), n_ghost=int(g[1]), n_interior=int(g[2])) for g in gathered],
                 "halo_bytes_sent_per_step_rank0": halo.bytes_sent_per_step,
+                "max_rel_error_vs_single_domain": verify,
                 "launch": azp._lib.last_launch(),
                 "tile_plan": pot.plan_info,
             },
