@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
             }
         }
     __syncthreads();
-    const bool bad = s_overflow || s_n > PLAN_MAX_STAGE || s_n > a.stage_stride || s_n > HC / 2;
+    const bool bad = s_overflow || s_n > PLAN_MAX_STAGE || s_n > a.stage_stride || s_n > HC * 5 / 8;
     const uint32_t n_stage = bad ? 0u : s_n;
     if (tid == 0)
         {
@@ -551,11 +551,10 @@ template<int TPP> static hipError_t launch_plan_kernels(int which, const PlanKAr
         hipLaunchKernelGGL((plan_chunks_kernel<TPP>), dim3(n_tiles), dim3(256), 0, s, k);
     else
         {
-        // a 4096-entry hash set (load factor <= 0.5) halves the LDS footprint and lets
-        // two build workgroups share a CU; large stage sets need the 8192-entry one
-        if (k.stage_stride <= 2048)
-            return launch_plan_build<TPP, 4096>(k, n_tiles, s);
-        return launch_plan_build<TPP, 8192>(k, n_tiles, s);
+        // a 4096-entry hash set holds every admissible stage set (<= 2,559 keys, load factor
+        // <= 0.625: ~1.8 probes per lookup) in half the LDS of an 8192-entry one, so two build
+        // workgroups share a CU up to ~2,300 staged particles per tile
+        return launch_plan_build<TPP, 4096>(k, n_tiles, s);
         }
     return hipGetLastError();
     }
@@ -668,7 +667,10 @@ static int plan_build_tpp(PairPlan& p, const azp_pair_args& args, uint32_t tpp, 
             }
         stride = p.max_stage + p.max_stage / 8 + 64; // the stride was the problem: grow and redo
         }
-    p.stage_stride_hint = p.max_stage + p.max_stage / 4 + 64;
+    // next build: a little head room only -- the stride also sizes the builder's LDS region for
+    // the staged positions (16 B per slot), and 25 % of it cost the builder half its occupancy
+    // once a tile staged ~2,000 particles; an overflow is retried with a larger stride anyway
+    p.stage_stride_hint = p.max_stage + p.max_stage / 16 + 32;
     p.total_stage = (uint64_t)p.n_tiles * stride;
     {
     float fm;

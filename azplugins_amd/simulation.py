@@ -32,7 +32,11 @@ class Integrator:
 class _Operations:
     def __init__(self):
         self.integrator = None
-        self.tuners = []  # e.g. azplugins_amd.sorter.ParticleSorter (HOOMD: sim.operations.tuners)
+        # HOOMD puts a ParticleSorter into sim.operations.tuners by default; so does this
+        # (remove it from the list, or set trigger_period = 0, to keep the initial order)
+        from .sorter import ParticleSorter
+
+        self.tuners = [ParticleSorter(trigger_period=200)]
 
 
 class Simulation:
@@ -119,7 +123,7 @@ class Simulation:
             # evaluation: every per-particle array that survives the step is permuted,
             # the forces are recomputed in the new order
             for tuner in self.operations.tuners:
-                if tuner.trigger_period > 0 and self.timestep % tuner.trigger_period == 0:
+                if tuner.trigger_period > 0 and self.timestep % tuner.trigger_period == 0 and st.n_ghost == 0:
                     tuner.sort(self)
             self._compute_forces()
             a.d_net_force = st.net_force.data_ptr()

@@ -36,18 +36,21 @@ class ParticleSorter:
         nb = (dims + b - 1) // b
         key = ((c[:, 2] // b) * nb[1] + (c[:, 1] // b)) * nb[0] + (c[:, 0] // b)
         inner = ((c[:, 2] % b) * b + (c[:, 1] % b)) * b + (c[:, 0] % b)
-        return key * (b * b * b) + inner
+        return (key * (b * b * b) + inner).to(torch.int32)  # < 2^31; int32 keys take torch's fast sort path
 
     def sort(self, sim):
         """Reorder the state of ``sim`` in place; returns the permutation applied
         (new index -> old index) as a device tensor."""
         import torch
 
+        import time
+
+        t0 = time.perf_counter()
         st = sim.state
         if st.n_ghost:
             raise _lib.AzpError("ParticleSorter: decomposed states keep their interior | boundary | ghost order")
         N = st.N
-        order = torch.argsort(self.keys(st), stable=True)
+        order = torch.sort(self.keys(st), stable=True).indices
         for name in ("pos", "vel", "orientation", "tag", "image"):
             a = getattr(st, name)
             a[:N] = a[:N].index_select(0, order)
@@ -60,4 +63,5 @@ class ParticleSorter:
         st.position_generation += 1
         st.order_generation = getattr(st, "order_generation", 0) + 1
         self.num_sorts += 1
+        self.host_seconds = getattr(self, "host_seconds", 0.0) + time.perf_counter() - t0  # launch-side time only
         return order

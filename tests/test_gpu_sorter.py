@@ -81,6 +81,7 @@ def test_sorter_in_run_loop_keeps_trajectory():
         pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=2.5, mode="shift")
         pot.params[("A", "A")] = cfg["params"]
         sim.operations.integrator = azp.Integrator(dt=0.002, forces=[pot], methods=[azp.ConstantVolume()])
+        sim.operations.tuners.clear()  # the default sorter (period 200) would not fire in 20 steps anyway
         if period:
             sim.operations.tuners.append(azp.ParticleSorter(trigger_period=period, particles_per_block=64))
         sim.run(20)

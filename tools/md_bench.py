@@ -21,7 +21,7 @@ ap.add_argument("--kT", type=float, default=1.0)
 ap.add_argument("--dt", type=float, default=0.005)
 ap.add_argument("--ncell", type=int, default=64)
 ap.add_argument("--no-plan", action="store_true")
-ap.add_argument("--sort-period", type=int, default=0, help="re-index the particles every this many steps (0 = never)")
+ap.add_argument("--sort-period", type=int, default=200, help="re-index the particles every this many steps (0 = never)")
 args = ap.parse_args()
 
 cfg = syn.config_north_star(args.ncell)
@@ -33,6 +33,7 @@ pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=cfg["r_cut"])
 pot.params[("A", "A")] = cfg["params"]
 pot.use_plan = not args.no_plan
 sim.operations.integrator = azp.Integrator(dt=args.dt, forces=[pot], methods=[azp.ConstantVolume()])
+sim.operations.tuners.clear()
 if args.sort_period:
     sim.operations.tuners.append(azp.ParticleSorter(trigger_period=args.sort_period))
 sim.run(0)
@@ -59,6 +60,6 @@ for _ in range(100):
 ev1.record()
 torch.cuda.synchronize()
 if args.sort_period:
-    print("particle sorts: %d" % sim.operations.tuners[0].num_sorts)
+    print("particle sorts: %d (%.1f ms of host time)" % (sim.operations.tuners[0].num_sorts, 1e3 * getattr(sim.operations.tuners[0], "host_seconds", 0.0)))
 print("force kernel on the final state: %.4f ms/launch; mean neighbors %.1f; plan %s" % (
     ev0.elapsed_time(ev1) / 100, nl.n_pairs / N, {k: pot.plan_info[k] for k in ("valid", "lds_slots", "max_stage")} if pot.use_plan else None))
