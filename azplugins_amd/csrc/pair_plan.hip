@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
     float4* s_p = reinterpret_cast<float4*>(list);
     __shared__ uint32_t s_n, s_overflow;
     __shared__ float s_far_margin;
-    __shared__ float s_rcutsq[64], s_rinnersq[64]; // up to 8 types cached; more types read the global tables
+    __shared__ float s_rcutsq[64], s_rinnersq[64], s_rfarsq[64]; // up to 8 types cached; more types read the global tables
     // bank-aware row ordering (TPP == 1): per wave 32 (part, bank) counters, 2 misfit
     // counters and the list of unclaimed positions
     __shared__ uint32_t s_bank_cnt[PLAN_BUILD_WAVES][68];
@@ -169,11 +169,17 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
         s_rcutsq[tid] = (float)a.rcutsq[tid];
         s_rinnersq[tid] = a.rinnersq ? (float)a.rinnersq[tid] : 0.f;
         }
-    // the classification is an ordering hint: single precision is enough
+    // single precision is enough for the classification (the in-range / buffer-shell split keeps a 1e-4 safety margin)
     const float bLx = (float)a.box.Lx, bLy = (float)a.box.Ly, bLz = (float)a.box.Lz;
     const float bLxi = (float)a.box.Lxinv, bLyi = (float)a.box.Lyinv, bLzi = (float)a.box.Lzinv;
     __syncthreads();
 
+    if (rc_cached && tid < a.ntypes * a.ntypes)
+        {
+        const float rb = sqrtf(fmaxf(s_rcutsq[tid], 0.f)) + s_far_margin; // s_far_margin: written before the barrier above
+        s_rfarsq[tid] = rb * rb * 1.0001f;
+        }
+    // (published by the barriers of the hash-set phase, long before the rows are compiled)
     // ---- hash-set of all neighbor indices of the tile: every wave takes rows
     // round-robin and issues all of a row's index loads before probing ----
     for (uint32_t p = wave; p < count; p += PLAN_BUILD_WAVES)
@@ -372,8 +378,15 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
                     near = in && !core;
                     if (!in)
                         {
-                        const float rb = sqrtf(fmaxf(rcsq, 0.f)) + s_far_margin;
-                        fa = !(s_far_margin > 0.f) || !(rsq >= rb * rb * 1.0001f);
+                        float rbsq; // (r_cut + far_margin)^2 (1 + 1e-4): where buffer shell B starts
+                        if (rc_cached)
+                            rbsq = s_rfarsq[tp];
+                        else
+                            {
+                            const float rb = sqrtf(fmaxf(rcsq, 0.f)) + s_far_margin;
+                            rbsq = rb * rb * 1.0001f;
+                            }
+                        fa = !(s_far_margin > 0.f) || !(rsq >= rbsq);
                         }
                     enc[it] = (((sidx + 1u) * 8u) << 2) | (core ? 0u : (near ? 1u : (fa ? 2u : 3u)));
                     }
