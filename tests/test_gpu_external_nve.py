@@ -153,3 +153,24 @@ def test_nve_steps_match_oracle(oracle):
     # energy conservation over the short run (sanity of the integrator itself)
     ke = 0.5 * (got_vel[:, :3] ** 2).sum()
     assert np.isfinite(ke) and nl.num_builds >= 1
+
+
+def test_halo_pack_matches_index_select():
+    """azp_halo_pack (send buffer of the ghost exchange) against torch.index_select."""
+    import ctypes as C
+
+    import torch
+
+    from azplugins_amd import _lib
+
+    g = torch.Generator().manual_seed(5)
+    stream = torch.cuda.current_stream().cuda_stream
+    for width in (4, 2, 6):
+        src = torch.rand((5000, width), dtype=torch.float64, generator=g).cuda()
+        idx = torch.randint(0, 5000, (3333,), generator=g).cuda()
+        dst = torch.full((3333, width), float("nan"), dtype=torch.float64, device="cuda:0")
+        _lib.check(_lib.lib().azp_halo_pack(idx.numel(), src.data_ptr(), idx.data_ptr(), width, dst.data_ptr(), stream), "pack")
+        assert torch.equal(dst, src.index_select(0, idx))
+    # a rank without peers packs nothing (null buffers are fine), odd row widths are rejected
+    assert _lib.lib().azp_halo_pack(0, None, None, 4, None, stream) == 0
+    assert _lib.lib().azp_halo_pack(10, src.data_ptr(), idx.data_ptr(), 3, dst.data_ptr(), stream) != 0
