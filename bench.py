@@ -221,6 +221,14 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
+    # always: a handful of launches over whole rows (no displacement information), so that both
+    # figures are in every JSON line; few enough not to move the profiler's per-kernel average
+    whole_rows_ms = None
+    if pot.use_displacement_bound and args.displace == 0.0 and not args.cycle_report:
+        pot.use_displacement_bound = False
+        whole_rows_ms = timed(reps=5)
+        pot.use_displacement_bound = True
+
     cycle = {}
     if args.cycle_report and args.displace == 0.0 and not args.sort_rows:
         pot.use_displacement_bound = False
@@ -267,6 +275,7 @@ def main():
             "note": "static list (the metric's definition): the kernel is told that no particle moved since the list was "
                     "built and stops each row before its Verlet-buffer entries (exact). --cycle-report times the same "
                     "list mid-cycle; profiles/r01d_cycle.json holds that run.",
+            "kernel_ms_whole_rows_no_displacement_information": whole_rows_ms,
             "kernel_ms_elsewhere_in_a_rebuild_cycle": cycle,
             "launch": launch,
             "tile_plan": pot.plan_info,
