@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(256) distance_check_kernel(uint32_t n, const d
                                                              const double* __restrict__ pos0, BoxDev box, double max_dist_sq,
                                                              uint32_t* __restrict__ flag, unsigned long long* __restrict__ max_bits)
     {
-    // grid-stride: a few thousand waves, each ending in at most one atomic
+    // grid-stride over at most 512 workgroups, each ending in at most one atomic
     double dsq_max = 0.0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         {
@@ -317,14 +317,20 @@ __global__ void __launch_bounds__(256) distance_check_kernel(uint32_t n, const d
         }
     for (int off = 32; off > 0; off >>= 1)
         dsq_max = fmax(dsq_max, __shfl_xor(dsq_max, off, 64));
+    // one atomic per workgroup: 16 k waves hammering one address cost more than the reads
+    __shared__ double s_wave_max[4];
     if ((threadIdx.x & 63) == 0)
+        s_wave_max[threadIdx.x >> 6] = dsq_max;
+    __syncthreads();
+    if (threadIdx.x == 0)
         {
+        dsq_max = fmax(fmax(s_wave_max[0], s_wave_max[1]), fmax(s_wave_max[2], s_wave_max[3]));
         if (dsq_max > max_dist_sq)
             atomicOr(flag, 1u);
         if (max_bits && dsq_max > 0.0)
             {
             // the bits of non-negative doubles order like the values; a plain read first
-            // keeps most waves off the atomic
+            // keeps most workgroups off the atomic
             const unsigned long long bits = (unsigned long long)__double_as_longlong(dsq_max);
             if (bits > *reinterpret_cast<volatile unsigned long long*>(max_bits))
                 atomicMax(max_bits, bits);
@@ -438,7 +444,7 @@ extern "C" int azp_nlist_distance_check(uint32_t n, const double* d_pos, const d
     if (n == 0)
         return AZP_SUCCESS;
     const uint32_t blocks = (n + 255u) / 256u;
-    hipLaunchKernelGGL(distance_check_kernel, dim3(blocks < 1024u ? blocks : 1024u), dim3(256), 0, static_cast<hipStream_t>(stream), n, d_pos,
+    hipLaunchKernelGGL(distance_check_kernel, dim3(blocks < 512u ? blocks : 512u), dim3(256), 0, static_cast<hipStream_t>(stream), n, d_pos,
                        d_pos_at_build, make_box_dev(*box), max_dist_sq, d_flag, d_max_dist_sq_bits);
     return (int)hipGetLastError();
     }
