@@ -43,7 +43,7 @@ class PairArgs(C.Structure):
         ("compute_virial", C.c_uint32),
         ("block_size", C.c_uint32),
         ("threads_per_particle", C.c_uint32),
-        ("_pad", C.c_uint32),
+        ("flags", C.c_uint32),
         ("range_first", C.c_uint32),
         ("range_count", C.c_uint32),
         ("r_list_max", C.c_double),
@@ -136,6 +136,17 @@ class PlanInfo(C.Structure):
     ]
 
 
+class AutoPlanStats(C.Structure):
+    _fields_ = [("calls", C.c_uint64), ("compiles", C.c_uint64), ("reuses", C.c_uint64), ("generic_fallbacks", C.c_uint64)]
+
+
+PAIR_FLAG_NO_AUTO_PLAN = 1
+
+
+class HaloField(C.Structure):
+    _fields_ = [("d_data", C.c_void_p), ("row_bytes", C.c_uint32), ("_pad", C.c_uint32)]
+
+
 class CellGrid(C.Structure):
     _fields_ = [("lo", C.c_double * 3), ("width", C.c_double * 3), ("dim", C.c_uint32 * 3), ("periodic", C.c_int32 * 3)]
 
@@ -192,6 +203,8 @@ SYMBOLS = {
     "azp_pair_plan_build": (C.c_int, [_VP, C.POINTER(PairArgs), _VP]),
     "azp_pair_plan_set_bank_order": (C.c_int, [_VP, C.c_int]),
     "azp_pair_plan_query": (C.c_int, [_VP, C.POINTER(PlanInfo)]),
+    "azp_pair_auto_plan_get_stats": (None, [C.POINTER(AutoPlanStats)]),
+    "azp_pair_auto_plan_clear": (None, []),
     "azp_pair_forces_planned_perturbed_lennard_jones": (C.c_int, [_VP, C.POINTER(PairArgs), _VP, _VP]),
     "azp_pair_forces_planned_hertz": (C.c_int, [_VP, C.POINTER(PairArgs), _VP, _VP]),
     "azp_pair_forces_planned_expanded_yukawa": (C.c_int, [_VP, C.POINTER(PairArgs), _VP, _VP]),
@@ -206,6 +219,8 @@ SYMBOLS = {
     "azp_nlist_count": (C.c_int, [C.POINTER(NlistArgs), _VP]),
     "azp_nlist_fill": (C.c_int, [C.POINTER(NlistArgs), _VP]),
     "azp_halo_pack": (C.c_int, [C.c_uint32, _VP, _VP, C.c_uint32, _VP, _VP]),
+    "azp_halo_pack_fields": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(HaloField), _VP, _VP, C.c_uint32, _VP]),
+    "azp_halo_unpack_fields": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(HaloField), _VP, C.c_uint32, _VP]),
     "azp_nlist_distance_check": (C.c_int, [C.c_uint32, _VP, _VP, C.POINTER(Box), _D, _VP, _VP, _VP]),
     "azp_external_planar_harmonic_barrier": (C.c_int, [C.POINTER(BarrierArgs), _VP]),
     "azp_external_spherical_harmonic_barrier": (C.c_int, [C.POINTER(BarrierArgs), _VP]),
@@ -292,6 +307,13 @@ class PairPlan:
                 self._h = None
         except Exception:
             pass
+
+
+def auto_plan_stats():
+    """Counters of the plan cache behind the HOOMD-signature entry points."""
+    st = AutoPlanStats()
+    lib().azp_pair_auto_plan_get_stats(C.byref(st))
+    return {f[0]: int(getattr(st, f[0])) for f in AutoPlanStats._fields_}
 
 
 def last_launch():

@@ -97,14 +97,31 @@ struct EvalPLJ
     // the core, -e_cut inside the cutoff) are the same constants for every pair, so
     // the pairs are only COUNTED here (one add-with-carry each) and the offsets are
     // applied once per particle in finish_split -- 4 FP64-rate ops fewer per pair
-    // than eval (no blended offset, no 64-bit select, one Newton step less).
+    // than eval (no blended offset, no 64-bit select, one Newton step less), and the
+    // reciprocals of a batch of four pairs share one v_rcp_f64 (rcp4).
     static constexpr bool kSplitEnergy = true;
-    static __device__ __forceinline__ void eval_split(const Coeff& c, double rsq, double& force_divr, double& pe_raw,
+    // Reciprocals of four squared separations from ONE v_rcp_f64: R = 1 / (a b c d) (seed
+    // + one Newton step, relative error ~2e-15 like fast_rcp1), then 1/(ab) = cd R,
+    // 1/(cd) = ab R, 1/a = b / (ab), ...: 9 multiplies + 1 rcp + 2 fma instead of 4 rcp +
+    // 8 fma. v_rcp_f64 issues at a quarter of the FP64 rate, so this is 60 instead of 96
+    // issue cycles per four pairs (tools/ubench.hip). Range: the padding slot sits at 1e30
+    // per axis (rsq = 3e60), so the product stays below 1e242; callers that re-image pairs
+    // park the padding at rsq = 1e60. A zero separation poisons the four pairs of ITS lane
+    // (the same particle's force, which is non-finite for r = 0 in any case).
+    static __device__ __forceinline__ void rcp4(const double (&a)[4], double (&inv)[4])
+        {
+        const double ab = a[0] * a[1], cd = a[2] * a[3];
+        const double R = fast_rcp1(ab * cd);
+        const double iab = cd * R, icd = ab * R;
+        inv[0] = a[1] * iab; inv[1] = a[0] * iab;
+        inv[2] = a[3] * icd; inv[3] = a[2] * icd;
+        }
+    // x = 1 / rsq is supplied by the caller (rcp4 or fast_rcp1).
+    static __device__ __forceinline__ void eval_split(const Coeff& c, double rsq, double x, double& force_divr, double& pe_raw,
                                                       uint32_t& n_wca, uint32_t& n_in)
         {
         const bool in = rsq < c.rcutsq;
         const bool wca = rsq < c.wca_rsq;
-        const double x = fast_rcp1(rsq);
         const double r2inv = __hiloint2double(in ? __double2hiint(x) : 0, __double2loint(x));
         const double m = __hiloint2double(wca ? 0x3ff00000 : 0, 0);
         const double r6inv = r2inv * r2inv * r2inv;
@@ -123,11 +140,10 @@ struct EvalPLJ
     // same constants for every pair, so only S2 = sum r6inv^2 and S1 = sum r6inv are
     // accumulated (2 ops instead of 3) and combined in finish_split; the pairs inside
     // the cutoff are counted only when the energy shift is non-zero (wave-uniform).
-    static __device__ __forceinline__ void eval_split_tail(const Coeff& c, double rsq, double& force_divr, double& s1,
+    static __device__ __forceinline__ void eval_split_tail(const Coeff& c, double rsq, double x, double& force_divr, double& s1,
                                                            double& s2, uint32_t& n_in, bool count_in)
         {
         const bool in = rsq < c.rcutsq;
-        const double x = fast_rcp1(rsq);
         const double r2inv = __hiloint2double(in ? __double2hiint(x) : 0, __double2loint(x));
         const double r6inv = r2inv * r2inv * r2inv;
         force_divr = r2inv * r6inv * __builtin_fma(c.c12_lam, r6inv, -c.c6_lam);

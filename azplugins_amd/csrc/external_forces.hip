@@ -208,13 +208,15 @@ extern "C" int azp_integrate_nve_step_two(const azp_nve_args* args, void* stream
     return azp::launch_nve<false>(args, stream);
     }
 
-// src/PlanarBarrierEvaluator.h:50-55: H inside [lo.y, hi.y) of the box
+// src/PlanarBarrierEvaluator.h:50-55: H inside [lo.y, hi.y), lo / hi = box.makeCoordinates((0,0,0)) /
+// ((1,1,1)). HOOMD's makeCoordinates shears the fractional point, y += yz * z, so for a
+// triclinic box the corners sit at y = -+(Ly / 2 + yz Lz / 2).
 extern "C" int azp_planar_barrier_valid(double H, const azp_box* box)
     {
     if (!box)
         return 0;
-    const double lo = -0.5 * box->L[1], hi = 0.5 * box->L[1];
-    return (H >= lo && H < hi) ? 1 : 0;
+    const double half = 0.5 * box->L[1] + box->tilt[2] * 0.5 * box->L[2];
+    return (H >= -half && H < half) ? 1 : 0;
     }
 // src/SphericalBarrierEvaluator.h:53-59: R >= 0 and 2 R <= nearest plane distance
 extern "C" int azp_spherical_barrier_valid(double R, const azp_box* box)
@@ -258,4 +260,89 @@ extern "C" int azp_halo_pack(uint32_t n, const double* d_src, const int64_t* d_i
     hipLaunchKernelGGL(azp::halo_pack_kernel, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n,
                        d_src, d_idx, row_doubles, d_dst);
     return (int)hipGetLastError();
+    }
+
+// ---- packed halo rows: several per-particle arrays in ONE send buffer ----
+namespace azp
+{
+struct HaloFieldsK
+    {
+    const unsigned char* src[AZP_HALO_MAX_FIELDS];
+    unsigned char* dst[AZP_HALO_MAX_FIELDS];
+    uint32_t row_bytes[AZP_HALO_MAX_FIELDS]; // multiple of 4
+    uint32_t offset[AZP_HALO_MAX_FIELDS];    // byte offset of the field inside a packed row
+    uint32_t n_fields;
+    uint32_t packed_row_bytes;               // multiple of 8
+    };
+
+// one lane per 4-byte word of a packed row
+template<bool PACK>
+__global__ void __launch_bounds__(256) halo_fields_kernel(uint32_t n, const HaloFieldsK f, const int64_t* __restrict__ idx,
+                                                          unsigned char* __restrict__ packed)
+    {
+    const uint32_t words = f.packed_row_bytes / 4;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)n * words)
+        return;
+    const uint32_t k = (uint32_t)(t / words), byte = (uint32_t)(t % words) * 4u;
+    uint32_t* slot = reinterpret_cast<uint32_t*>(packed + (uint64_t)k * f.packed_row_bytes + byte);
+    for (uint32_t c = 0; c < f.n_fields; ++c)
+        {
+        if (byte >= f.offset[c] && byte < f.offset[c] + f.row_bytes[c])
+            {
+            if (PACK)
+                *slot = *reinterpret_cast<const uint32_t*>(f.src[c] + (uint64_t)idx[k] * f.row_bytes[c] + (byte - f.offset[c]));
+            else
+                *reinterpret_cast<uint32_t*>(f.dst[c] + (uint64_t)k * f.row_bytes[c] + (byte - f.offset[c])) = *slot;
+            return;
+            }
+        }
+    if (PACK)
+        *slot = 0u; // padding between fields
+    }
+
+template<bool PACK> int launch_halo_fields(uint32_t n, uint32_t n_fields, const azp_halo_field* fields, const int64_t* d_idx, void* d_packed,
+                                           uint32_t packed_row_bytes, void* stream)
+    {
+    if (n == 0)
+        return AZP_SUCCESS;
+    if (!fields || !d_packed || n_fields == 0 || n_fields > AZP_HALO_MAX_FIELDS || (PACK && !d_idx) || (packed_row_bytes & 7u))
+        return AZP_ERROR_INVALID_ARGUMENT;
+    HaloFieldsK k;
+    uint32_t off = 0;
+    for (uint32_t c = 0; c < AZP_HALO_MAX_FIELDS; ++c)
+        {
+        k.src[c] = nullptr; k.dst[c] = nullptr; k.row_bytes[c] = 0; k.offset[c] = 0;
+        }
+    for (uint32_t c = 0; c < n_fields; ++c)
+        {
+        if (!fields[c].d_data || fields[c].row_bytes == 0 || (fields[c].row_bytes & 3u))
+            return AZP_ERROR_INVALID_ARGUMENT;
+        k.src[c] = static_cast<const unsigned char*>(fields[c].d_data);
+        k.dst[c] = static_cast<unsigned char*>(fields[c].d_data);
+        k.row_bytes[c] = fields[c].row_bytes;
+        k.offset[c] = off;
+        off += (fields[c].row_bytes + 7u) & ~7u; // every field starts on an 8-byte boundary
+        }
+    if (off != packed_row_bytes)
+        return AZP_ERROR_INVALID_ARGUMENT;
+    k.n_fields = n_fields;
+    k.packed_row_bytes = packed_row_bytes;
+    const uint64_t lanes = (uint64_t)n * (packed_row_bytes / 4);
+    hipLaunchKernelGGL(halo_fields_kernel<PACK>, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n, k,
+                       d_idx, static_cast<unsigned char*>(d_packed));
+    return (int)hipGetLastError();
+    }
+} // namespace azp
+
+extern "C" int azp_halo_pack_fields(uint32_t n, uint32_t n_fields, const azp_halo_field* fields, const int64_t* d_idx, void* d_packed,
+                                    uint32_t packed_row_bytes, void* stream)
+    {
+    return azp::launch_halo_fields<true>(n, n_fields, fields, d_idx, d_packed, packed_row_bytes, stream);
+    }
+
+extern "C" int azp_halo_unpack_fields(uint32_t n, uint32_t n_fields, const azp_halo_field* fields, const void* d_packed,
+                                      uint32_t packed_row_bytes, void* stream)
+    {
+    return azp::launch_halo_fields<false>(n, n_fields, fields, nullptr, const_cast<void*>(d_packed), packed_row_bytes, stream);
     }

@@ -8,10 +8,10 @@
 //           set exceeds PLAN_MAX_STAGE particles -- e.g. unsorted particle order --
 //           invalidates the plan); the staged positions are loaded into LDS; every
 //           row entry is translated (hash lookup) to a u16 byte offset, classified
-//           core / near / buffer shell A / buffer shell B, placed bank-aware inside
+//           core / near / buffer shell 0 .. PLAN_SHELLS - 1, placed bank-aware inside
 //           its class, and the row is written as 16-byte chunks in the force
 //           kernel's own lane order; per slice the chunk counts up to the end of the
-//           in-range entries and of shell A are kept for the displacement bound.
+//           in-range entries and of every shell are kept for the displacement bound.
 // The host-side scan makes plan build a sync point, like HOOMD's own
 // neighbor-list overflow check.
 #include <algorithm>
@@ -30,8 +30,10 @@ struct PlanKArgs
     const uint64_t* head_list;
     const double* rcutsq;
     const double* rinnersq; // optional (may be null): "core" class radius^2 per type pair
-    uint32_t* slice_Kskip;  // 2 per slice, zeroed before the build kernel
-    double r_list_max;      // caller's hint (r_cut_max + 2 r_buff), 0 = unknown: no shell B
+    uint32_t* slice_Kend;   // PLAN_SHELLS + 1 per slice, zeroed before the build kernel
+    double r_list_max;      // caller's hint (r_cut_max + 2 r_buff), 0 = unknown
+    double r_list_estimate; // used when r_list_max is unknown: an estimate of r_cut_max + r_buff (0: one shell holds
+                            // the whole buffer)
     uint32_t bank_order;    // bank-aware row order (build option)
     uint32_t* tile_nstage;
     uint64_t* tile_head;
@@ -133,11 +135,11 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
     // (x, y, z, type): they only feed the near/far ordering hint, never a force
     float4* s_p = reinterpret_cast<float4*>(list);
     __shared__ uint32_t s_n, s_overflow;
-    __shared__ float s_far_margin;
-    __shared__ float s_rcutsq[64], s_rinnersq[64], s_rfarsq[64]; // up to 8 types cached; more types read the global tables
-    // bank-aware row ordering (TPP == 1): per wave 32 (part, bank) counters, 2 misfit
-    // counters and the list of unclaimed positions
-    __shared__ uint32_t s_bank_cnt[PLAN_BUILD_WAVES][68];
+    __shared__ float s_shell_w;   // shell width w = r_buff / PLAN_SHELLS (0: no hint, no shells)
+    __shared__ float s_rcutsq[64], s_rinnersq[64], s_rcut[64]; // up to 8 types cached; more types read the global tables
+    // bank-aware row ordering (TPP == 1): per wave 16 bank counters and one misfit counter
+    // per class, and the list of unclaimed positions
+    __shared__ uint32_t s_bank_cnt[PLAN_BUILD_WAVES][PLAN_CLASSES * 17];
     __shared__ uint16_t s_holes[PLAN_BUILD_WAVES][PLAN_ROWBUF];
 
     const uint32_t tid = threadIdx.x;
@@ -154,15 +156,17 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
     if (tid == 0)
         {
         s_n = 0; s_overflow = 0;
-        // buffer shell B = the outer half of the Verlet buffer: r >= r_cut + r_buff / 2 with
-        // r_buff = (r_list_max - r_cut_max) / 2; published to the host through flags[3]
+        // the Verlet buffer r_cut <= r < r_cut + r_buff is cut into PLAN_SHELLS shells of width
+        // w = r_buff / PLAN_SHELLS, r_buff = (r_list_max - r_cut_max) / 2; published to the host
+        // through flags[3]
         double rc_max_sq = 0.0;
         for (uint32_t t = 0; t < a.ntypes * a.ntypes; ++t)
             rc_max_sq = fmax(rc_max_sq, a.rcutsq[t]);
-        const double m = (a.r_list_max > 0.0) ? 0.25 * (a.r_list_max - sqrt(rc_max_sq)) : 0.0;
-        s_far_margin = (m > 0.0) ? (float)m : 0.f;
+        const double w = (a.r_list_max > 0.0) ? 0.5 * (a.r_list_max - sqrt(rc_max_sq)) / PLAN_SHELLS
+                                              : (a.r_list_estimate > 0.0 ? (a.r_list_estimate - sqrt(rc_max_sq)) / PLAN_SHELLS : 0.0);
+        s_shell_w = (w > 0.0) ? (float)w : 0.f;
         if (blockIdx.x == 0)
-            a.flags[3] = (uint32_t)__float_as_int(s_far_margin);
+            a.flags[3] = (uint32_t)__float_as_int(s_shell_w);
         }
     if (rc_cached && tid < a.ntypes * a.ntypes)
         {
@@ -175,10 +179,7 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
     __syncthreads();
 
     if (rc_cached && tid < a.ntypes * a.ntypes)
-        {
-        const float rb = sqrtf(fmaxf(s_rcutsq[tid], 0.f)) + s_far_margin; // s_far_margin: written before the barrier above
-        s_rfarsq[tid] = rb * rb * 1.0001f;
-        }
+        s_rcut[tid] = sqrtf(fmaxf(s_rcutsq[tid], 0.f));
     // (published by the barriers of the hash-set phase, long before the rows are compiled)
     // ---- hash-set of all neighbor indices of the tile: every wave takes rows
     // round-robin and issues all of a row's index loads before probing ----
@@ -305,6 +306,8 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
     // inside its part, and the u16 offsets land in the wave's row buffer.
     uint16_t* rowbuf = w_rowbuf + wave * PLAN_ROWBUF;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    float rsq_listed_max = 0.f; // largest listed separation^2 seen by this lane (flags[4]: a hint for callers
+                                // that do not know r_cut + r_buff, e.g. the cache behind the HOOMD-signature entry)
     for (uint32_t p = wave; p < (uint32_t)TB; p += PLAN_BUILD_WAVES)
         {
         const uint32_t fwave = p / PW, pl = p % PW; // force-kernel wave (slice) and particle inside it
@@ -338,21 +341,25 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
         const uint32_t iters = (n + 63u) >> 6;
         // pass A: translate + classify. Classes: 0 core (inside the evaluator's inner
         // radius hint, e.g. the WCA core of PerturbedLJ), 1 near (inside the cutoff
-        // now), 2 buffer shell A (r_cut <= r < r_cut + far_margin), 3 buffer shell B
-        // (beyond). Rows are written core | near | A | B. The core / near split is an
-        // ordering hint; the near / A / B split lets the force kernel stop early when
-        // the caller bounds the displacement since this build, so it must be
+        // now), 2 + s: buffer shell s (r_cut + s w <= r, s < PLAN_SHELLS). Rows are
+        // written core | near | shell 0 | shell 1 | ... The core / near split is an
+        // ordering hint; the near / shell splits let the force kernel stop early when
+        // the caller bounds the displacement since this build, so they must be
         // CONSERVATIVE: the single-precision separation (relative error < 1e-5) has to
-        // clear the boundary by a factor 1 + 1e-4 before an entry counts as outside it.
-        uint32_t n_core = 0, n_near = 0, n_fa = 0;
-        uint32_t enc[ITERS]; // (offset << 2) | class, 0 = no entry
+        // clear a boundary by a factor 1 + 5e-5 before an entry counts as outside it.
+        uint32_t cnt_cls[PLAN_CLASSES]; // entries per class (wave-uniform)
+#pragma unroll
+        for (uint32_t cidx = 0; cidx < PLAN_CLASSES; ++cidx)
+            cnt_cls[cidx] = 0;
+        const float shell_winv = (s_shell_w > 0.f) ? 1.0f / s_shell_w : 0.f;
+        uint32_t enc[ITERS]; // (offset << 4) | class, 0 = no entry
 #pragma unroll
         for (int it = 0; it < ITERS; ++it)
             {
             enc[it] = 0;
             if ((uint32_t)it < iters)
                 {
-                bool near = false, core = false, fa = false;
+                uint32_t cls = PLAN_CLASSES; // no entry
                 if (jj[it] != PLAN_EMPTY)
                     {
                     const uint32_t sidx = slot_of[plan_find<HC>(table, jj[it])];
@@ -371,38 +378,40 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
                         dx = (float)ddx; dy = (float)ddy; dz = (float)ddz;
                         }
                     const float rsq = dx * dx + dy * dy + dz * dz;
+                    rsq_listed_max = fmaxf(rsq_listed_max, rsq);
                     const uint32_t tp = trow + (uint32_t)__float_as_int(q.w);
                     const float rcsq = rc_cached ? s_rcutsq[tp] : (float)a.rcutsq[tp];
                     const bool in = !(rsq >= rcsq * 1.0001f); // "inside, or too close to call"
-                    core = in && rsq < (rc_cached ? s_rinnersq[tp] : (a.rinnersq ? (float)a.rinnersq[tp] : 0.f));
-                    near = in && !core;
-                    if (!in)
+                    if (in)
+                        cls = (rsq < (rc_cached ? s_rinnersq[tp] : (a.rinnersq ? (float)a.rinnersq[tp] : 0.f))) ? 0u : 1u;
+                    else
                         {
-                        float rbsq; // (r_cut + far_margin)^2 (1 + 1e-4): where buffer shell B starts
-                        if (rc_cached)
-                            rbsq = s_rfarsq[tp];
-                        else
-                            {
-                            const float rb = sqrtf(fmaxf(rcsq, 0.f)) + s_far_margin;
-                            rbsq = rb * rb * 1.0001f;
-                            }
-                        fa = !(s_far_margin > 0.f) || !(rsq >= rbsq);
+                        // shell s <=> the separation is certainly >= r_cut + s w: the single-precision
+                        // r is shortened by 5e-5 (its own error is < 1e-5) before it is binned
+                        const float rc = rc_cached ? s_rcut[tp] : sqrtf(fmaxf(rcsq, 0.f));
+                        const float sh = floorf((sqrtf(rsq) * 0.99995f - rc) * shell_winv);
+                        cls = 2u + (uint32_t)fminf(fmaxf(sh, 0.f), (float)(PLAN_SHELLS - 1)); // NaN (w = 0) -> shell 0
                         }
-                    enc[it] = (((sidx + 1u) * 8u) << 2) | (core ? 0u : (near ? 1u : (fa ? 2u : 3u)));
+                    enc[it] = (((sidx + 1u) * 8u) << 4) | cls;
                     }
-                n_core += (uint32_t)__popcll(__ballot(core));
-                n_near += (uint32_t)__popcll(__ballot(near));
-                n_fa += (uint32_t)__popcll(__ballot(fa));
+#pragma unroll
+                for (uint32_t cidx = 0; cidx < PLAN_CLASSES; ++cidx)
+                    cnt_cls[cidx] += (uint32_t)__popcll(__ballot(cls == cidx));
                 }
             }
+        uint32_t seg[PLAN_CLASSES + 1]; // class cidx occupies row positions [seg[cidx], seg[cidx + 1])
+        seg[0] = 0;
+#pragma unroll
+        for (uint32_t cidx = 0; cidx < PLAN_CLASSES; ++cidx)
+            seg[cidx + 1] = seg[cidx] + cnt_cls[cidx];
         if (lane == 0 && p < count)
             {
-            // chunks a force-kernel wave must process to cover every in-range entry /
-            // every entry up to the end of shell A, over the rows of its slice
-            atomicMax(&a.slice_Kskip[2 * slice], (n_core + n_near + 8u * TPP - 1u) / (8u * TPP));
-            atomicMax(&a.slice_Kskip[2 * slice + 1], (n_core + n_near + n_fa + 8u * TPP - 1u) / (8u * TPP));
+            // chunks a force-kernel wave must process to cover every in-range entry [0] / every
+            // entry up to the end of shell s [1 + s], over the rows of its slice
+#pragma unroll
+            for (uint32_t sh = 0; sh <= PLAN_SHELLS; ++sh)
+                atomicMax(&a.slice_Kend[(PLAN_SHELLS + 1) * slice + sh], (seg[2 + sh] + 8u * TPP - 1u) / (8u * TPP));
             }
-        const uint32_t seg[5] = {0u, n_core, n_core + n_near, n_core + n_near + n_fa, n};
         if (TPP == 1 && PLAN_BANK_ORDER && a.bank_order)
             {
             // pass B (bank-aware): lane l of the force kernel reads its row entry q at
@@ -417,7 +426,7 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
             // (tools/lds_bench.hip): 10.7 -> 7.4 LDS cycles per wave read.
             uint32_t* cnt = s_bank_cnt[wave];
             uint16_t* holes = s_holes[wave];
-            for (uint32_t t = lane; t < 68; t += 64)
+            for (uint32_t t = lane; t < PLAN_CLASSES * 17; t += 64)
                 cnt[t] = 0;
             for (uint32_t t = lane; t < row_cap; t += 64)
                 rowbuf[t] = (t < n) ? (uint16_t)0xffffu : (uint16_t)0; // unclaimed | padding
@@ -428,20 +437,31 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
                 {
                 if ((uint32_t)it < iters && enc[it] != 0)
                     {
-                    const uint32_t cls = enc[it] & 3u;
-                    const uint32_t off = enc[it] >> 2, bank = (off >> 3) & 15u;
+                    const uint32_t cls = enc[it] & 15u;
+                    const uint32_t off = enc[it] >> 4, bank = (off >> 3) & 15u;
                     const uint32_t r = atomicAdd(&cnt[cls * 16u + bank], 1u);
-                    const uint32_t b = seg[cls], e = seg[cls + 1];
-                    const uint32_t q = b + ((bank - pl - b) & 15u) + 16u * r;
-                    if (q < e)
+                    uint32_t bs = 0, es = 0;
+#pragma unroll
+                    for (uint32_t cidx = 0; cidx < PLAN_CLASSES; ++cidx)
+                        if (cls == cidx)
+                            {
+                            bs = seg[cidx];
+                            es = seg[cidx + 1];
+                            }
+                    const uint32_t q = bs + ((bank - pl - bs) & 15u) + 16u * r;
+                    if (q < es)
                         rowbuf[q] = (uint16_t)off;
                     else
                         misfit |= 1u << it;
                     }
                 }
             __builtin_amdgcn_wave_barrier();
-            // unclaimed positions, in order (class by class)
-            uint32_t n_holes = 0, holes_c0 = 0, holes_c01 = 0, holes_c012 = 0;
+            // unclaimed positions, in order (class by class); holes_lt[cidx] = holes before class cidx
+            uint32_t n_holes = 0;
+            uint32_t holes_lt[PLAN_CLASSES];
+#pragma unroll
+            for (uint32_t cidx = 0; cidx < PLAN_CLASSES; ++cidx)
+                holes_lt[cidx] = 0;
             for (uint32_t t0 = 0; t0 < n; t0 += 64)
                 {
                 const uint32_t t = t0 + lane;
@@ -450,9 +470,9 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
                 if (hole)
                     holes[n_holes + (uint32_t)__popcll(m & lt_mask)] = (uint16_t)t;
                 n_holes += (uint32_t)__popcll(m);
-                holes_c0 += (uint32_t)__popcll(__ballot(hole && t < seg[1]));
-                holes_c01 += (uint32_t)__popcll(__ballot(hole && t < seg[2]));
-                holes_c012 += (uint32_t)__popcll(__ballot(hole && t < seg[3]));
+#pragma unroll
+                for (uint32_t cidx = 1; cidx < PLAN_CLASSES; ++cidx)
+                    holes_lt[cidx] += (uint32_t)__popcll(__ballot(hole && t < seg[cidx]));
                 }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -460,28 +480,35 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
                 {
                 if (misfit & (1u << it))
                     {
-                    const uint32_t cls = enc[it] & 3u;
-                    const uint32_t m = atomicAdd(&cnt[64u + cls], 1u)
-                                       + (cls == 0 ? 0u : (cls == 1 ? holes_c0 : (cls == 2 ? holes_c01 : holes_c012)));
-                    rowbuf[holes[m]] = (uint16_t)(enc[it] >> 2);
+                    const uint32_t cls = enc[it] & 15u;
+                    uint32_t before = 0;
+#pragma unroll
+                    for (uint32_t cidx = 0; cidx < PLAN_CLASSES; ++cidx)
+                        if (cls == cidx)
+                            before = holes_lt[cidx];
+                    const uint32_t m = atomicAdd(&cnt[PLAN_CLASSES * 16u + cls], 1u) + before;
+                    rowbuf[holes[m]] = (uint16_t)(enc[it] >> 4);
                     }
                 }
             __builtin_amdgcn_wave_barrier();
             }
         else
             {
-            // pass B: stable four-way partition into the row buffer
-            uint32_t base[4] = {seg[0], seg[1], seg[2], seg[3]};
+            // pass B: stable partition into the row buffer, class by class
+            uint32_t base[PLAN_CLASSES];
+#pragma unroll
+            for (uint32_t cidx = 0; cidx < PLAN_CLASSES; ++cidx)
+                base[cidx] = seg[cidx];
 #pragma unroll
             for (int it = 0; it < ITERS; ++it)
                 {
                 if ((uint32_t)it < iters)
                     {
                     const bool valid = enc[it] != 0;
-                    const uint32_t cls = enc[it] & 3u;
+                    const uint32_t cls = enc[it] & 15u;
                     uint32_t posn = 0;
 #pragma unroll
-                    for (uint32_t cidx = 0; cidx < 4; ++cidx)
+                    for (uint32_t cidx = 0; cidx < PLAN_CLASSES; ++cidx)
                         {
                         const uint64_t m = __ballot(valid && cls == cidx);
                         if (cls == cidx)
@@ -489,7 +516,7 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
                         base[cidx] += (uint32_t)__popcll(m);
                         }
                     if (valid)
-                        rowbuf[posn] = (uint16_t)(enc[it] >> 2);
+                        rowbuf[posn] = (uint16_t)(enc[it] >> 4);
                     }
                 }
             // pad to the slice's rectangle with the dummy slot
@@ -506,6 +533,10 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
             out[(uint64_t)(cidx / TPP) * 64 + pl * TPP + (cidx % TPP)] = rb4[cidx];
         __builtin_amdgcn_wave_barrier();
         }
+    for (int off = 32; off > 0; off >>= 1)
+        rsq_listed_max = fmaxf(rsq_listed_max, __shfl_xor(rsq_listed_max, off, 64));
+    if (lane == 0)
+        atomicMax(&a.flags[4], (uint32_t)__float_as_int(rsq_listed_max)); // non-negative floats order like their bits
     }
 
 template<class T> static hipError_t ensure(T*& ptr, size_t& cap, size_t need)
@@ -524,13 +555,13 @@ template<class T> static hipError_t ensure(T*& ptr, size_t& cap, size_t need)
     return e;
     }
 
-static void plan_free(PairPlan& p)
+void plan_free(PairPlan& p)
     {
     if (p.d_tile_nstage) (void)hipFree(p.d_tile_nstage);
     if (p.d_tile_head) (void)hipFree(p.d_tile_head);
     if (p.d_stage_idx) (void)hipFree(p.d_stage_idx);
     if (p.d_slice_K) (void)hipFree(p.d_slice_K);
-    if (p.d_slice_Kskip) (void)hipFree(p.d_slice_Kskip);
+    if (p.d_slice_Kend) (void)hipFree(p.d_slice_Kend);
     if (p.d_slice_head) (void)hipFree(p.d_slice_head);
     if (p.d_cnl) (void)hipFree(p.d_cnl);
     if (p.d_flags) (void)hipFree(p.d_flags);
@@ -547,7 +578,7 @@ template<int TPP, uint32_t HC> static hipError_t launch_plan_build(const PlanKAr
     {
     const size_t lds = plan_lds_bytes(HC, k.stage_stride);
     auto kern = plan_build_kernel<TPP, HC>;
-    if (lds + 12 * 1024 > 64 * 1024) // + the kernel's static LDS (bank counters, hole lists)
+    if (lds + 16 * 1024 > 64 * 1024) // + the kernel's static LDS (bank counters, hole lists: ~14.5 KiB)
         {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -603,11 +634,11 @@ static int plan_build_tpp(PairPlan& p, const azp_pair_args& args, uint32_t tpp, 
     AZP_HIP_TRY(ensure(p.d_tile_nstage, p.cap_tiles, p.n_tiles));
     AZP_HIP_TRY(ensure(p.d_tile_head, cap_heads_t, p.n_tiles));
     AZP_HIP_TRY(ensure(p.d_slice_K, p.cap_slices, p.n_slices));
-    AZP_HIP_TRY(ensure(p.d_slice_Kskip, p.cap_kskip, 2 * (size_t)p.n_slices));
+    AZP_HIP_TRY(ensure(p.d_slice_Kend, p.cap_kend, (PLAN_SHELLS + 1) * (size_t)p.n_slices));
     AZP_HIP_TRY(ensure(p.d_slice_head, cap_heads_s, p.n_slices));
-    size_t cap_flags = p.d_flags ? 4 : 0;
-    AZP_HIP_TRY(ensure(p.d_flags, cap_flags, 4));
-    AZP_HIP_TRY(hipMemsetAsync(p.d_flags, 0, 4 * sizeof(uint32_t), s));
+    size_t cap_flags = p.d_flags ? 8 : 0;
+    AZP_HIP_TRY(ensure(p.d_flags, cap_flags, 8));
+    AZP_HIP_TRY(hipMemsetAsync(p.d_flags, 0, 8 * sizeof(uint32_t), s));
 
     PlanKArgs k;
     k.pos = args.d_pos;
@@ -616,10 +647,11 @@ static int plan_build_tpp(PairPlan& p, const azp_pair_args& args, uint32_t tpp, 
     k.head_list = args.d_head_list;
     k.rcutsq = args.d_rcutsq;
     k.rinnersq = args.d_rinnersq;
-    k.slice_Kskip = p.d_slice_Kskip;
-    // buffer shell B: the outer half of the Verlet buffer (r_buff = (r_list_max - r_cut_max) / 2 is
-    // not known here, so the caller's r_list_max hint and the largest cutoff are used when given)
+    k.slice_Kend = p.d_slice_Kend;
+    // buffer shells: r_buff = (r_list_max - r_cut_max) / 2 is not known here, so the caller's
+    // r_list_max hint and the largest cutoff are used when given
     k.r_list_max = args.r_list_max;
+    k.r_list_estimate = p.shell_hint_r_list;
     k.bank_order = p.bank_order ? 1u : 0u;
     k.tile_nstage = p.d_tile_nstage;
     k.tile_head = p.d_tile_head;
@@ -635,7 +667,7 @@ static int plan_build_tpp(PairPlan& p, const azp_pair_args& args, uint32_t tpp, 
     AZP_HIP_TRY(launch_plan(tpp, 0, k, p.n_tiles, s));
 
     std::vector<uint32_t> h_K(p.n_slices);
-    uint32_t h_flags[4];
+    uint32_t h_flags[8];
     AZP_HIP_TRY(hipMemcpyAsync(h_K.data(), p.d_slice_K, sizeof(uint32_t) * p.n_slices, hipMemcpyDeviceToHost, s));
     AZP_HIP_TRY(hipMemcpyAsync(h_flags, p.d_flags, sizeof(h_flags), hipMemcpyDeviceToHost, s));
     AZP_HIP_TRY(hipStreamSynchronize(s));
@@ -660,8 +692,8 @@ static int plan_build_tpp(PairPlan& p, const azp_pair_args& args, uint32_t tpp, 
         {
         stride = std::min<uint32_t>((stride + 63u) & ~63u, PLAN_MAX_STAGE + 1);
         AZP_HIP_TRY(ensure(p.d_stage_idx, p.cap_stage, (size_t)p.n_tiles * stride));
-        AZP_HIP_TRY(hipMemsetAsync(p.d_flags, 0, 4 * sizeof(uint32_t), s));
-        AZP_HIP_TRY(hipMemsetAsync(p.d_slice_Kskip, 0, 2 * sizeof(uint32_t) * p.n_slices, s));
+        AZP_HIP_TRY(hipMemsetAsync(p.d_flags, 0, 8 * sizeof(uint32_t), s));
+        AZP_HIP_TRY(hipMemsetAsync(p.d_slice_Kend, 0, (PLAN_SHELLS + 1) * sizeof(uint32_t) * p.n_slices, s));
         k.stage_idx = p.d_stage_idx;
         k.cnl = p.d_cnl;
         k.stage_stride = stride;
@@ -688,7 +720,9 @@ static int plan_build_tpp(PairPlan& p, const azp_pair_args& args, uint32_t tpp, 
     {
     float fm;
     __builtin_memcpy(&fm, &h_flags[3], sizeof(fm));
-    p.far_margin = fm;
+    p.shell_width = fm;
+    __builtin_memcpy(&fm, &h_flags[4], sizeof(fm));
+    p.max_listed_r = std::sqrt(fm);
     }
     p.cap = plan_cap_for(p.max_stage);
     p.valid = true;

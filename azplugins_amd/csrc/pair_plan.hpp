@@ -21,6 +21,7 @@
 // The plan is rebuilt whenever the neighbor list is rebuilt (every ~10-20 MD
 // steps) and reused by every force call in between.
 #pragma once
+#include <cmath>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -37,6 +38,9 @@ constexpr uint32_t PLAN_BITMAP_WORDS = 80;    // 2560 slots / 32
 constexpr uint32_t PLAN_ROWBUF = 512;         // compiled entries per row the builder can hold (rows longer than
                                               // this invalidate the plan)
 constexpr double PLAN_FAR = 1.0e30;          // coordinate of the dummy slot
+constexpr uint32_t PLAN_SHELLS = 8;          // the Verlet-buffer entries of every row are ordered into this many shells
+                                              // of equal width by their separation when the plan is built
+constexpr uint32_t PLAN_CLASSES = PLAN_SHELLS + 2; // row order: core | near | shell 0 | ... | shell PLAN_SHELLS - 1
 
 struct PairPlan
     {
@@ -60,12 +64,17 @@ struct PairPlan
     uint64_t* d_tile_head = nullptr;       // n_tiles
     uint32_t* d_stage_idx = nullptr;       // total_stage
     uint32_t* d_slice_K = nullptr;         // n_slices
-    uint32_t* d_slice_Kskip = nullptr;     // 2 x n_slices: chunks up to the end of the in-range entries / of buffer shell A
-    double far_margin = 0.0;               // m of buffer shell B: entries with r_build >= r_cut + m (0: no shell B)
+    uint32_t* d_slice_Kend = nullptr;      // (PLAN_SHELLS + 1) x n_slices: chunks up to the end of the in-range entries [0] /
+                                           // of buffer shell s [1 + s]
+    double shell_width = 0.0;              // w: shell s holds entries with r_build >= r_cut + s w (certainly); 0: no shells
+                                           // (no r_list_max hint at build time: all buffer entries sit in shell 0)
+    float max_listed_r = 0.f;              // largest separation of a listed pair when the plan was built (single precision)
+    double shell_hint_r_list = 0.0;        // > 0 and no azp_pair_args.r_list_max: an estimate of r_cut_max + r_buff that sizes
+                                           // the shells (any value is exact; it only sets how finely the buffer is cut)
     uint64_t* d_slice_head = nullptr;      // n_slices (chunk units)
     uint4* d_cnl = nullptr;                // total_chunks * 64
-    uint32_t* d_flags = nullptr;           // [1] stage overflow, [2] max staged set
-    size_t cap_tiles = 0, cap_slices = 0, cap_stage = 0, cap_cnl = 0, cap_kskip = 0;
+    uint32_t* d_flags = nullptr;           // [1] stage overflow, [2] max staged set, [3] shell width, [4] max listed r^2 (float bits)
+    size_t cap_tiles = 0, cap_slices = 0, cap_stage = 0, cap_cnl = 0, cap_kend = 0;
     uint64_t builds = 0;
     bool bank_order = true;         // build option (azp_pair_plan_set_bank_order)
     uint32_t stage_stride_hint = 0; // stage_idx entries to reserve per tile next time (last max + 25 %)
@@ -73,6 +82,24 @@ struct PairPlan
     // runs: interior | boundary) picks the LDS variant from the tiles it covers
     std::vector<uint32_t> h_tile_nstage;
     };
+
+// Buffer shells a launch has to walk, from the caller's displacement bound: an entry of
+// shell s was at least r_cut + s w away when the plan was built, so it cannot be in range
+// while 2 x bound <= s w. Exact, not a heuristic.
+inline uint32_t plan_shells_for(const PairPlan& plan, const azp_pair_args& args)
+    {
+    if (!args.has_displacement_bound || !(args.displacement_bound >= 0.0))
+        return PLAN_SHELLS; // unknown: whole rows
+    if (args.displacement_bound == 0.0)
+        return 0;
+    if (!(plan.shell_width > 0.0))
+        return PLAN_SHELLS;
+    const double n = std::ceil(2.0 * args.displacement_bound * (1.0 + 1e-12) / plan.shell_width);
+    return n >= (double)PLAN_SHELLS ? PLAN_SHELLS : (uint32_t)n;
+    }
+
+int plan_build(PairPlan& p, const azp_pair_args& args, hipStream_t s); // pair_plan.hip
+void plan_free(PairPlan& p);
 
 inline uint32_t plan_cap_for(uint32_t max_stage)
     {

@@ -42,11 +42,22 @@ struct TiledKArgs
     const uint64_t* tile_head;
     const uint32_t* stage_idx;
     const uint32_t* slice_K;
-    const uint32_t* slice_Kskip; // 2 per slice: chunks covering the in-range entries / up to the end of buffer shell A
-    uint32_t skip_level;         // 0 whole rows, 1 stop before buffer shell B, 2 stop before the buffer entries
+    const uint32_t* slice_Kend;  // PLAN_SHELLS + 1 per slice: chunks covering the in-range entries [0] / the entries up to
+                                 // the end of buffer shell s [1 + s]
+    uint32_t n_shells;           // buffer shells this launch has to walk: 0 = none (positions as at plan build) ...
+                                 // PLAN_SHELLS = whole rows
     const uint64_t* slice_head;
     const uint4* cnl;
     };
+
+// Stride (in slots) between the x, y and z arrays in LDS. CAP itself lets the compiler fuse the
+// x and y gathers of a pair into one ds_read2st64_b64 (half the LDS rate of ds_read_b64,
+// MI355X_MICROARCH.md LDS table); AZP_TILE_SOA_PAD = 1 makes the stride odd so they stay
+// two ds_read_b64.
+#ifndef AZP_TILE_SOA_PAD
+#define AZP_TILE_SOA_PAD 0
+#endif
+#define AZP_TILE_STRIDE(CAP) ((CAP) + AZP_TILE_SOA_PAD)
 
 #ifndef AZP_TILE_BATCH
 #define AZP_TILE_BATCH 4 // pairs per register batch: 4 = half a chunk, 8 = a whole chunk
@@ -85,8 +96,8 @@ template<int CAP, int H> __device__ __forceinline__ void tile_gather(TileBatch& 
         b.x[e] = (double)b.off[e]; b.y[e] = 1.0; b.z[e] = 2.0; // ablation 2: no LDS gathers
 #else
         b.x[e] = *reinterpret_cast<const double*>(bx + b.off[e]);
-        b.y[e] = *reinterpret_cast<const double*>(bx + b.off[e] + CAP * 8);
-        b.z[e] = *reinterpret_cast<const double*>(bx + b.off[e] + CAP * 16);
+        b.y[e] = *reinterpret_cast<const double*>(bx + b.off[e] + AZP_TILE_STRIDE(CAP) * 8);
+        b.z[e] = *reinterpret_cast<const double*>(bx + b.off[e] + AZP_TILE_STRIDE(CAP) * 16);
 #endif
         }
     }
@@ -115,7 +126,8 @@ __device__ __forceinline__ void tile_compute(const TileBatch& b, const TiledKArg
             min_image(a.p.box, dx[e], dy[e], dz[e]);
         rsq[e] = __builtin_fma(dz[e], dz[e], __builtin_fma(dy[e], dy[e], dx[e] * dx[e]));
         if (WRAP)
-            rsq[e] = (b.off[e] == 0) ? 1.0e300 : rsq[e]; // the minimum image would fold the padding slot back into the box
+            rsq[e] = (b.off[e] == 0) ? 1.0e60 : rsq[e]; // the minimum image would fold the padding slot back into the box
+                                                        // (1e60: out of range, and a product of four stays finite for rcp4)
         any_in = any_in || (rsq[e] < rcutsq_max);
         }
 #if defined(AZP_ABLATE) && (AZP_ABLATE == 3)
@@ -124,9 +136,28 @@ __device__ __forceinline__ void tile_compute(const TileBatch& b, const TiledKArg
 #endif
     if (!__any(any_in))
         return;
+#ifdef AZP_TILE_LANE_MASK
+    // experiment: lanes without a pair in range in this batch sit the evaluator out (EXEC
+    // mask): the same issue cycles, fewer active FP64 lanes (the kernel runs into the power
+    // limit)
+    if (!any_in)
+        return;
+#endif
     double fd[NB]; // force / r of the batch (SPLIT: filled by one of two forms of the evaluator)
     if constexpr (SPLIT)
         {
+        // one v_rcp_f64 for the four pairs of the batch (EvalPLJ::rcp4)
+        double x[NB];
+#ifndef AZP_NO_RCP4
+        if constexpr (NB == 4)
+            E::rcp4(rsq, x);
+        else
+#endif
+            {
+#pragma unroll
+            for (int e = 0; e < NB; ++e)
+                x[e] = fast_rcp1(rsq[e]);
+            }
         // rows list the pairs inside the evaluator's core first (plan hint), so beyond
         // the first chunks no lane of the wave has one and the cheaper tail-only form
         // applies to the whole batch (exact: tested on the actual separations). Both
@@ -141,13 +172,13 @@ __device__ __forceinline__ void tile_compute(const TileBatch& b, const TiledKArg
             const bool count_in = c0.tail_add != 0.0;
 #pragma unroll
             for (int e = 0; e < NB; ++e)
-                E::eval_split_tail(c0, rsq[e], fd[e], es[0], es[1], n_in, count_in);
+                E::eval_split_tail(c0, rsq[e], x[e], fd[e], es[0], es[1], n_in, count_in);
             }
         else
             {
 #pragma unroll
             for (int e = 0; e < NB; ++e)
-                E::eval_split(c0, rsq[e], fd[e], pe, n_core, n_in);
+                E::eval_split(c0, rsq[e], x[e], fd[e], pe, n_core, n_in);
             }
         }
 #pragma unroll
@@ -264,10 +295,10 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
     constexpr int PW = 64 / TPP;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     double* s_x = reinterpret_cast<double*>(s_raw);
-    double* s_y = s_x + CAP;
-    double* s_z = s_y + CAP;
-    int* s_t = reinterpret_cast<int*>(s_z + CAP); // CAP ints, only when !SINGLE
-    Coeff* s_coeff = reinterpret_cast<Coeff*>(s_raw + (size_t)CAP * (SINGLE ? 24 : 28));
+    double* s_y = s_x + AZP_TILE_STRIDE(CAP);
+    double* s_z = s_y + AZP_TILE_STRIDE(CAP);
+    int* s_t = reinterpret_cast<int*>(s_z + AZP_TILE_STRIDE(CAP)); // CAP ints, only when !SINGLE
+    Coeff* s_coeff = reinterpret_cast<Coeff*>(s_raw + (size_t)AZP_TILE_STRIDE(CAP) * 24 + (SINGLE ? 0 : (size_t)CAP * 4 + 8));
     double* s_ronsq = reinterpret_cast<double*>(s_coeff + (SINGLE ? 0 : a.p.ntypes * a.p.ntypes));
 
     const uint32_t tid = threadIdx.x;
@@ -333,6 +364,12 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
     // loads of every round first, then every position load (two dependent HBM round
     // trips per tile instead of two per 256 staged particles -- the staging took 17 of
     // a tile's 41 us when it was written as a plain loop, tools/timeline.py).
+    // Without the r_list_max hint (callers that only have HOOMD's pair_args_t) the tile is
+    // "compact" when every staged image and every member lies within L / 4 of the reference
+    // particle on each periodic axis: then any two of them are closer than L / 2 per axis, so
+    // the staged image of a neighbor IS its minimum image for every member.
+    const bool no_hint = !(a.p.r_list_max > 0.0);
+    bool far_from_c = false;
     {
     constexpr int ROUNDS = (CAP + 255) / 256; // n_stage < CAP
     uint32_t sj[ROUNDS];
@@ -379,6 +416,10 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
                 if (a.p.box.px) x = __builtin_fma(-a.p.box.Lx, rint((x - c.x) * a.p.box.Lxinv), x);
                 if (a.p.box.py) y = __builtin_fma(-a.p.box.Ly, rint((y - c.y) * a.p.box.Lyinv), y);
                 if (a.p.box.pz) z = __builtin_fma(-a.p.box.Lz, rint((z - c.z) * a.p.box.Lzinv), z);
+                if (no_hint)
+                    far_from_c = far_from_c || (a.p.box.px && fabs(x - c.x) >= 0.25 * a.p.box.Lx)
+                                 || (a.p.box.py && fabs(y - c.y) >= 0.25 * a.p.box.Ly)
+                                 || (a.p.box.pz && fabs(z - c.z) >= 0.25 * a.p.box.Lz);
                 }
             s_x[sidx + 1] = x; s_y[sidx + 1] = y; s_z[sidx + 1] = z;
             if (!SINGLE)
@@ -393,7 +434,7 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
     // Fast path condition, per tile: every member is closer to c than L/2 minus
     // the largest possible pair separation, so the staged image of each listed
     // neighbor IS its minimum image. Otherwise every pair is re-imaged.
-    bool lane_wide = (a.p.r_list_max <= 0.0) || a.p.box.triclinic;
+    bool lane_wide = far_from_c || a.p.box.triclinic;
     if (active)
         {
         const double4 p = own;
@@ -403,9 +444,12 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
             if (a.p.box.px) x = __builtin_fma(-a.p.box.Lx, rint((x - c.x) * a.p.box.Lxinv), x);
             if (a.p.box.py) y = __builtin_fma(-a.p.box.Ly, rint((y - c.y) * a.p.box.Lyinv), y);
             if (a.p.box.pz) z = __builtin_fma(-a.p.box.Lz, rint((z - c.z) * a.p.box.Lzinv), z);
-            lane_wide = lane_wide || (a.p.box.px && fabs(x - c.x) + a.p.r_list_max >= 0.5 * a.p.box.Lx)
-                        || (a.p.box.py && fabs(y - c.y) + a.p.r_list_max >= 0.5 * a.p.box.Ly)
-                        || (a.p.box.pz && fabs(z - c.z) + a.p.r_list_max >= 0.5 * a.p.box.Lz);
+            // (without the hint r_reach = L / 4: the member itself has to be within L / 4 of c)
+            const double rx = no_hint ? 0.25 * a.p.box.Lx : a.p.r_list_max, ry = no_hint ? 0.25 * a.p.box.Ly : a.p.r_list_max,
+                         rz = no_hint ? 0.25 * a.p.box.Lz : a.p.r_list_max;
+            lane_wide = lane_wide || (a.p.box.px && fabs(x - c.x) + rx >= 0.5 * a.p.box.Lx)
+                        || (a.p.box.py && fabs(y - c.y) + ry >= 0.5 * a.p.box.Ly)
+                        || (a.p.box.pz && fabs(z - c.z) + rz >= 0.5 * a.p.box.Lz);
             }
         pi = make_double3(x, y, z);
         typei = type_from_w(p.w);
@@ -426,7 +470,7 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
     // scalar trip count (the loop counter and the chunk address stay in SGPRs). With a
     // displacement bound from the caller the row ends early: entries that were at
     // least 2 x bound outside the cutoff when the plan was built cannot be in range.
-    const uint32_t K = to_uniform(a.skip_level == 0 ? a.slice_K[slice] : a.slice_Kskip[2 * slice + (a.skip_level == 1 ? 1 : 0)]);
+    const uint32_t K = to_uniform(a.n_shells >= PLAN_SHELLS ? a.slice_K[slice] : a.slice_Kend[(PLAN_SHELLS + 1) * slice + a.n_shells]);
     // wave-uniform slice base (SGPRs) + lane: the loads use scalar-base addressing
     const uint64_t slice_head = to_uniform(a.slice_head[slice]);
     const char* __restrict__ slice_base = reinterpret_cast<const char*>(a.cnl + slice_head * 64ull);
@@ -491,13 +535,8 @@ int launch_tiled_instance2(const PairPlan& plan, const azp_pair_args& args, cons
     k.tile_head = plan.d_tile_head;
     k.stage_idx = plan.d_stage_idx;
     k.slice_K = plan.d_slice_K;
-    k.slice_Kskip = plan.d_slice_Kskip;
-    k.skip_level = 0;
-    if (args.has_displacement_bound && args.displacement_bound == 0.0)
-        k.skip_level = 2;
-    else if (args.has_displacement_bound && args.displacement_bound > 0.0 && plan.far_margin > 0.0
-             && 2.0 * args.displacement_bound <= plan.far_margin)
-        k.skip_level = 1;
+    k.slice_Kend = plan.d_slice_Kend;
+    k.n_shells = plan_shells_for(plan, args);
     k.slice_head = plan.d_slice_head;
     k.cnl = plan.d_cnl;
     // sub-range launches are rounded outwards to whole tiles (a tile computed by
@@ -508,7 +547,7 @@ int launch_tiled_instance2(const PairPlan& plan, const azp_pair_args& args, cons
     k.p.end = (t1 * tb < args.N) ? t1 * tb : args.N;
     const uint32_t nblocks = (t1 - t0 + 7u) & ~7u;
     k.p.nblocks_padded = nblocks;
-    size_t lds = (size_t)CAP * (SINGLE ? 24 : 28);
+    size_t lds = (size_t)AZP_TILE_STRIDE(CAP) * 24 + (SINGLE ? 0 : (size_t)CAP * 4 + 8);
     if (!SINGLE)
         lds += (sizeof(typename E::Coeff) + sizeof(double)) * (size_t)args.ntypes * args.ntypes;
     if (lds > 160 * 1024)

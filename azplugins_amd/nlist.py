@@ -30,11 +30,18 @@ class NeighborList:
         self.max_neigh = 0
         self._row_capacity = 0    # > 0: rows of fixed capacity (single-pass rebuilds)
         self.single_pass = True
+        self._consumer_version = 0        # bumped when a consumer's r_cut matrix changes
+        self._built_consumer_version = None
 
     # -- consumers (pair potentials) register their r_cut matrices ---------
     def _add_consumer(self, force):
         if force not in self._consumers:
             self._consumers.append(force)
+            self._consumers_changed()
+
+    def _consumers_changed(self):
+        """A consumer was added or changed its r_cut: the next compute rebuilds the list."""
+        self._consumer_version += 1
 
     def _r_cut_matrix(self, ntypes):
         rc = np.zeros((ntypes, ntypes))
@@ -62,6 +69,8 @@ class Cell(NeighborList):
         self._compact = compact
         if getattr(state, "order_generation", 0) != getattr(self, "_order_generation", 0):
             force = True  # the particles were re-indexed (ParticleSorter): every stored index is stale
+        if self._built_consumer_version != self._consumer_version:
+            force = True  # built for another r_cut matrix
         if not force and self.nlist is not None:
             if self._built_generation == state.position_generation:
                 return
@@ -96,6 +105,15 @@ class Cell(NeighborList):
         if getattr(self, "_disp_generation", None) == state.position_generation:
             return self._disp
         return None
+
+    def assume_displacement(self, state, bound):
+        """Benchmark / replay hook: the caller vouches that the current positions are within
+        ``bound`` of the positions the list was built for (e.g. a stored snapshot of a run whose
+        distance check returned exactly that), so no distance check runs for them."""
+        if self.nlist is None:
+            raise _lib.AzpError("assume_displacement: the list has not been built")
+        self._built_generation = state.position_generation
+        self._disp, self._disp_generation = float(bound), state.position_generation
 
     def _build(self, state):
         import torch
@@ -191,6 +209,7 @@ class Cell(NeighborList):
         self.n_neigh, self.head_list, self.nlist, self.size = n_neigh, head, nlist, size
         self._pos_at_build = state.pos[:n_total].clone()
         self._order_generation = getattr(state, "order_generation", 0)
+        self._built_consumer_version = self._consumer_version
         self._disp, self._disp_generation = 0.0, state.position_generation
         self.num_builds += 1
         self._keep = (rlistsq, cell_of, cell_sorted, order, cell_start, keep)

@@ -35,12 +35,13 @@ class Pair(Force):
         self.nlist = nlist
         self._mode = mode
         self.params = TypeParameter("params", self._schema, 2, self._mark_dirty, self._readback)
-        self.r_cut = ScalarTypeParameter("r_cut", default_r_cut, self._mark_dirty)
+        self.r_cut = ScalarTypeParameter("r_cut", default_r_cut, self._r_cut_changed)
         self.r_on = ScalarTypeParameter("r_on", default_r_on, self._mark_dirty)
         self.threads_per_particle = 0   # 0 = library heuristic (HOOMD autotunes this)
         self.block_size = 0
         self.use_plan = True            # LDS-staged tile kernel when the neighbor list can be tiled
         self.use_displacement_bound = True  # let it stop rows early while particles have barely moved (exact)
+        self.plan_bank_order = None     # None: bank-aware rows only for long-lived lists (below); True / False: always / never
         self._plan = None
         self._plan_builds = None
         self._tables = None
@@ -61,6 +62,15 @@ class Pair(Force):
     def _mark_dirty(self):
         self._tables = None
         self._computed_generation = None
+        # the tile plan orders and classifies rows against the cutoffs / inner radii it was
+        # built with: recompile it with the new tables
+        self._plan_builds = None
+
+    def _r_cut_changed(self):
+        """HOOMD rebuilds the neighbor list when a consumer's r_cut matrix changes: the
+        list on hand was built for the old r_cut + buffer."""
+        self._mark_dirty()
+        self.nlist._consumers_changed()
 
     # -- raw parameter structs (host side of the C ABI) ------------------------
     def _pack(self, d):
@@ -151,6 +161,8 @@ class Pair(Force):
         a.compute_virial = 1 if self.compute_virial else 0
         a.block_size = self.block_size
         a.threads_per_particle = self.threads_per_particle
+        if not self.use_plan:
+            a.flags = _lib.PAIR_FLAG_NO_AUTO_PLAN  # use_plan = False means the generic kernel, not libazp's own plan cache
         a.r_list_max = nl.r_list_max
         # displacement of any particle since the PLAN was built <= displacement since the list was
         # built (now) + the same quantity at the time the plan was built (0 in the usual flow)
@@ -193,7 +205,7 @@ class Pair(Force):
                 # bank-aware rows pay off only for lists that live long (include/azp.h): keep them
                 # for the first build and whenever the previous list served >= 50 force calls
                 calls = getattr(self, "_calls_since_plan", None)
-                self._plan.set_bank_order(calls is None or calls >= 50)
+                self._plan.set_bank_order((calls is None or calls >= 50) if self.plan_bank_order is None else self.plan_bank_order)
                 self._calls_since_plan = 0
                 self._plan.build(a, stream)
                 a.range_first, a.range_count = first, count

@@ -13,11 +13,27 @@ from . import _lib
 from .state import State
 
 
+class All:
+    """``hoomd.filter.All``: every particle. The only filter the NVE kernels implement."""
+
+    def __eq__(self, other):
+        return isinstance(other, All)
+
+    def __hash__(self):
+        return hash("All")
+
+
 class ConstantVolume:
-    """NVE integration method (velocity Verlet) on all particles."""
+    """NVE integration method (velocity Verlet) on all particles
+    (``hoomd.md.methods.ConstantVolume(filter=hoomd.filter.All())`` without a
+    thermostat, the dummy integrator of the reference's tests,
+    src/pytest/test_pair.py:325-327). Any other filter is rejected: the kernels
+    integrate all N particles."""
 
     def __init__(self, filter=None):
-        self.filter = filter
+        if filter is not None and not isinstance(filter, All):
+            raise _lib.AzpError("ConstantVolume: only filter=All() (or None) is supported, got %r" % (filter,))
+        self.filter = All() if filter is None else filter
 
 
 class Integrator:
@@ -101,6 +117,8 @@ class Simulation:
         self._compute_forces()
         if steps == 0 or not integ.methods:
             return
+        if len(integ.methods) != 1 or not isinstance(integ.methods[0], ConstantVolume):
+            raise _lib.AzpError("Integrator.methods must hold exactly one ConstantVolume (all particles); got %r" % (integ.methods,))
         import ctypes as C
 
         a = _lib.NVEArgs()

@@ -8,7 +8,12 @@ force at N=1,048,576, rho*=0.8, r_cut=3.0 (FP64, full neighbor list, buffer
 0.4), plus the achieved algorithmic HBM GB/s against the MI355X roofline.
 
 A "step" is one pass of the force kernel(s) over the whole system on a static
-neighbor list, inputs resident in HBM. Prints ONE JSON line on rank 0.
+neighbor list (built once, never rebuilt in the timed region), inputs resident in
+HBM. The positions the kernel sees cycle through the steps of one rebuild cycle of
+a real MD run (the list is built for step 0; HOOMD's distance check would rebuild
+it after the last one), so the figure is the mean over a cycle and not the
+best-case step right after a rebuild; --static times that step alone. Prints ONE
+JSON line on rank 0.
 """
 
 import argparse
@@ -80,16 +85,14 @@ def displace_particles(state, amplitude, seed):
     state.position_generation += 1
 
 
-def cpu_baseline(workload, reps=5):
+def cpu_baseline(workload, reps=3):
     """HOOMD-equivalent CPU loop restated (oracle): half neighbor list, third-law
     scatter, FP64, ONE core (HOOMD's per-rank CPU execution model), timed on
-    this host. Bounded sample: the same lattice, density, potential and cutoff
-    at 1/8 of the particle count (per-particle cost is size-independent)."""
+    this host on the workload itself (the full N; ~1 s per repetition)."""
     import oracle
-    from azplugins_amd import synthetic as syn
 
-    cfg = syn.config_north_star(32) if workload.startswith("ns") else syn.config_plj_sc(40)
-    pos = syn.pos4(cfg["xyz"])
+    cfg = make_workload(workload)
+    pos = syn_pos4(cfg)
     box = oracle.make_box(cfg["L"])
     params = oracle.pack_pair_params(cfg["potential"], cfg["params"])
     nl = oracle.build_nlist(pos, box, cfg["r_cut"] + cfg["r_buff"], half=True)
@@ -101,8 +104,9 @@ def cpu_baseline(workload, reps=5):
     t = float(np.median(ts))
     N = pos.shape[0]
     out = dict(value=N / t, unit="particle-steps/s", cores=1, kind="port",
-               sample="%s: same lattice/density/potential, N=%d (1/8 of the workload), half list, median of %d "
-                      "reps; oracle = HOOMD-equivalent loop restated, not the HOOMD binary" % (cfg["name"], N, reps))
+               sample="%s: the workload itself, N=%d, half list (built outside the timed region), median of %d "
+                      "repetitions of the force loop; oracle = HOOMD-equivalent loop restated, not the HOOMD binary" % (cfg["name"], N, reps))
+    del nl
     # best-effort all-core figure (OpenMP over particles, full list), on this process's CPU share
     try:
         ncores = len(os.sched_getaffinity(0))
@@ -119,6 +123,50 @@ def cpu_baseline(workload, reps=5):
     return out
 
 
+def syn_pos4(cfg):
+    from azplugins_amd import synthetic as syn
+
+    return syn.pos4(cfg["xyz"])
+
+
+def committed_counter(kernel, workload, name):
+    """Mean per-launch value of a PMC counter from the committed rocprofv3 passes
+    (profiles/r*_counters.json), or None."""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters.json")), reverse=True):
+        try:
+            d = json.load(open(f)).get(kernel)
+        except (OSError, ValueError):
+            continue
+        if d and d.get("workload", "").lower() == workload.lower() and name in d:
+            return float(d[name]), os.path.basename(f)
+    return None, None
+
+
+def record_md_cycle(sim, nl, kT, seed):
+    """Positions of one neighbor-list rebuild cycle of a real NVE run: Maxwell velocities at
+    kT on the workload's snapshot, velocity Verlet until HOOMD's distance check (a particle
+    moved farther than r_buff / 2) asks for the next rebuild. Returns the position tensors
+    after steps 0, 1, ... (step 0 = the snapshot the list is built for)."""
+    import azplugins_amd as azp
+
+    st = sim.state
+    integ = sim.operations.integrator
+    integ.methods = [azp.ConstantVolume()]
+    sim.operations.tuners.clear()
+    sim.thermalize_particle_momenta(kT, seed=seed)
+    builds = nl.num_builds
+    snaps = [st.pos.clone()]
+    while len(snaps) < 64:
+        sim.run(1)
+        if nl.num_builds != builds:
+            break
+        snaps.append(st.pos.clone())
+    integ.methods = []
+    return snaps
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,16 +178,20 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="none", choices=["none", "shift", "xplor"])
     ap.add_argument("--no-plan", action="store_true", help="generic kernel only (no LDS-staged tile plan)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1 GPUs: weak = 2^20 particles per GPU (default), strong = 2^20 in total")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="N > 1 GPUs: strong = 2^20 particles in total (default, the north star's criterion), weak = 2^20 per GPU")
+    ap.add_argument("--static", action="store_true",
+                    help="time only the snapshot the list was built for (displacement bound 0: round 1's headline state) "
+                         "instead of a rebuild cycle of an MD run")
+    ap.add_argument("--kT", type=float, default=1.0, help="temperature of the Maxwell velocities that drive the recorded MD cycle")
+    ap.add_argument("--bank-order", type=int, default=0,
+                    help="1: bank-aware row order in the tile plan (what a list that lives >= 50 force calls gets); "
+                         "default 0, as in an MD run that rebuilds every ~8 steps")
     ap.add_argument("--displace", type=float, default=0.0,
                     help="sensitivity run: after the neighbor list and plan are built, move every particle by a hashed "
                          "random vector of length <= DISPLACE * r_buff / 2 (0 = the snapshot the list was built for, as "
                          "the metric is defined; 1 = the moment before the next rebuild)")
     ap.add_argument("--sort-rows", action="store_true", help="experiment: sort every neighbor row by index before planning")
-    ap.add_argument("--cycle-report", action="store_true",
-                    help="after the timed region, also time the kernel without displacement information and with every "
-                         "particle displaced by 0.5 / 0.9 x r_buff/2 (same list and plan); reported in config")
     ap.add_argument("--no-displacement-bound", action="store_true",
                     help="do not tell the planned kernel how far particles moved since the list was built (it then walks "
                          "whole rows, Verlet-buffer entries included)")
@@ -194,23 +246,57 @@ def main():
         pot.compute(0)
         assert nl.num_builds == 1, "the displacement must not trigger a neighbor-list rebuild"
 
-    for _ in range(args.warmup):
+    # ---- the states the kernel is timed on: one rebuild cycle of a real MD run ----
+    # (args.static: the round-1 figure, the snapshot the list was built for, no particle moved)
+    st = sim.state
+    r_buff = cfg["r_buff"]
+    if args.static or args.displace > 0.0 or args.sort_rows:
+        snaps, bounds = [st.pos], [nl.displacement_bound(st)]
+    else:
+        x0 = st.pos.clone()
+        snaps = record_md_cycle(sim, nl, args.kT, seed=7)
+        # list + plan for step 0, built as an MD run builds them (rows of fixed capacity; the
+        # bank-aware row order only pays for lists that live >= 50 force calls: off)
+        st.pos = x0
+        st.position_generation += 1
+        pot.plan_bank_order = bool(args.bank_order)
+        nl.compute(st, force=True)
         pot.compute(0)
+        builds = nl.num_builds
+        bounds = []
+        for x in snaps:  # the distance check of every step, as the MD run made it
+            st.pos = x
+            st.position_generation += 1
+            pot.compute(0)
+            assert nl.num_builds == builds, "a recorded step triggered a rebuild"
+            bounds.append(nl.displacement_bound(st))
+    n_states = len(snaps)
+
+    def set_state(k):
+        st.pos = snaps[k]
+        st.position_generation += 1
+        nl.assume_displacement(st, bounds[k])  # known from the recorded run: no distance-check kernel in the timed loop
+
+    def step(k):
+        set_state(k % n_states)
+        pot.compute(0)
+
+    for k in range(args.warmup):
+        step(k)
     torch.cuda.synchronize()
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(args.steps):
-        pot.compute(0)
+    for k in range(args.steps):
+        step(k)
     ev1.record()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
     ms_per_step = wall * 1e3 / args.steps
 
-    # the same list part-way through a rebuild cycle (outside the timed region): every particle
-    # displaced by <= 0.5 x r_buff/2, then by <= 0.9 x r_buff/2; and with no displacement information
+    # ---- side figures, outside the timed region (>= 40 launches each) ----
     def timed(reps=40):
         pot.compute(0)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -221,27 +307,37 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    # always: a handful of launches over whole rows (no displacement information), so that both
-    # figures are in every JSON line; few enough not to move the profiler's per-kernel average
-    whole_rows_ms = None
-    if pot.use_displacement_bound and args.displace == 0.0 and not args.cycle_report:
+    by_step = []
+    for k in range(n_states):
+        set_state(k)
+        by_step.append(dict(step=k, displacement_bound=bounds[k], bound_over_half_buffer=bounds[k] / (0.5 * r_buff), kernel_ms=timed()))
+    set_state(0)
+    side = {}
+    if pot.use_displacement_bound and not args.sort_rows and args.displace == 0.0:
+        side["static_list_bound_0_ms"] = timed()  # round 1's headline state
         pot.use_displacement_bound = False
-        whole_rows_ms = timed(reps=5)
+        side["whole_rows_no_displacement_information_ms"] = timed()
         pot.use_displacement_bound = True
-
-    cycle = {}
-    if args.cycle_report and args.displace == 0.0 and not args.sort_rows:
-        pot.use_displacement_bound = False
-        cycle["no_displacement_information_ms"] = timed()
-        pot.use_displacement_bound = not args.no_displacement_bound
-        x0 = sim.state.pos.clone()
-        for f in (0.5, 0.9):
-            sim.state.pos.copy_(x0)
-            displace_particles(sim.state, f * 0.5 * cfg["r_buff"], seed=11)
-            cycle["displaced_%.1f_x_half_buffer_ms" % f] = timed()
-        assert nl.num_builds == 1
-        sim.state.pos.copy_(x0)
-        sim.state.position_generation += 1
+        if n_states > 1:
+            # round 1's synthetic mid-cycle states: EVERY particle displaced by a random vector of
+            # length <= f r_buff / 2 (harsher than an MD step, where only the fastest particles get there)
+            keep = st.pos
+            for f in (0.5, 0.9):
+                st.pos = snaps[0].clone()
+                displace_particles(st, f * 0.5 * r_buff, seed=11)
+                pot.compute(0)  # runs the distance check
+                assert nl.num_builds == builds
+                side["every_particle_displaced_%.1f_x_half_buffer_ms" % f] = timed()
+            st.pos = keep
+            st.position_generation += 1
+            # the same cycle with the bank-aware row order (what a list that lives >= 50 calls gets)
+            pot.plan_bank_order = not bool(args.bank_order)
+            pot._plan_builds = None
+            alt = []
+            for k in range(n_states):
+                set_state(k)
+                alt.append(timed(20))
+            side["cycle_mean_ms_with_bank_order_%s" % ("on" if pot.plan_bank_order else "off")] = float(np.mean(alt))
 
     value = N * args.steps / wall
     b_alg = alg_bytes_per_particle(mean_neigh)
@@ -250,6 +346,12 @@ def main():
     kernel_name = ("azp::pair_forces_tiled_kernel<EvalPLJ>" if (pot.plan_info or {}).get("valid")
                    else "azp::pair_forces_kernel<EvalPLJ>")
     traffic, traffic_src = measured_traffic(kernel_name, cfg["name"])
+    valu, valu_src = committed_counter(kernel_name, cfg["name"], "SQ_INSTS_VALU")
+    cycle_desc = ("static list: the snapshot the list was built for, displacement bound 0" if n_states == 1 else
+                  "one neighbor-list rebuild cycle of an NVE run (Maxwell velocities kT=%.2f on the workload's snapshot, dt=0.005; "
+                  "%d steps until HOOMD's distance check asks for a rebuild); timed step k uses the positions of cycle step "
+                  "k mod %d with the displacement bound that step's distance check returned; list and plan built once for "
+                  "step 0, not rebuilt" % (args.kT, n_states, n_states))
     out = {
         "metric": "particle-steps/sec, PerturbedLennardJones pair force",
         "value": value,
@@ -259,24 +361,21 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": args.scaling,
+        "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
             "workload": "%s: PerturbedLennardJones N=%d rho*=0.8 r_cut=%.1f buffer=%.1f mode=%s, jittered %s lattice, "
-                        "full neighbor list <n>=%.2f" % (cfg["name"], N, cfg["r_cut"], cfg["r_buff"], args.mode,
+                        "full neighbor list <n>=%.2f" % (cfg["name"], N, cfg["r_cut"], r_buff, args.mode,
                                                         "FCC" if args.workload.startswith("ns") else "SC", mean_neigh),
             "N": N,
             "mean_neighbors": mean_neigh,
-            "displacement_since_list_build": "every particle moved by <= %.3g (= %.2f x r_buff/2)"
-                                             % (args.displace * 0.5 * cfg["r_buff"], args.displace),
+            "states_timed": cycle_desc,
+            "kernel_ms_by_cycle_step": by_step,
+            "kernel_ms_other_states": side,
+            "plan_bank_order": bool(pot.plan_bank_order) if n_states > 1 else None,
             "displacement_bound_passed": bool(pot.use_displacement_bound),
-            "note": "static list (the metric's definition): the kernel is told that no particle moved since the list was "
-                    "built and stops each row before its Verlet-buffer entries (exact). --cycle-report times the same "
-                    "list mid-cycle; profiles/r01d_cycle.json holds that run.",
-            "kernel_ms_whole_rows_no_displacement_information": whole_rows_ms,
-            "kernel_ms_elsewhere_in_a_rebuild_cycle": cycle,
             "launch": launch,
             "tile_plan": pot.plan_info,
             "parallelism": "1 GPU",
@@ -293,8 +392,21 @@ def main():
             "kernel": kernel_name,
             "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_particle": b_alg,
+            "note": "achieved = SURVEY 8(d) algorithmic bytes / mean launch time over the cycle. The bytes this kernel really moves "
+                    "(traffic) are about half of that (16-bit compiled list); it is limited by FP64 VALU issue and LDS gather "
+                    "cycles, not by HBM: see roofline_fp64_issue",
         },
     }
+    if valu is not None:
+        lane_ops = valu * 64.0 / (kernel_ms * 1e-3) / 1e12
+        peak = 256 * 4 * 16 * 2.4e9 / 1e12  # 256 CUs x 4 SIMDs x 16 FP64 lanes per clock x 2.4 GHz (= 78.6 TFLOP/s FMA peak / 2)
+        out["roofline_fp64_issue"] = {
+            "bound": "fp64-issue", "achieved": lane_ops, "peak": peak, "unit": "T lane-instructions/s", "frac": lane_ops / peak,
+            "valu_wave_instructions_per_launch": valu, "source": valu_src,
+            "note": "VALU wave-instructions per launch (rocprofv3 --pmc SQ_INSTS_VALU, committed pass) x 64 lanes / the launch time "
+                    "measured here, against the FP64 vector issue peak at the 2.4 GHz nominal clock; the chip holds ~1.5-1.8 GHz "
+                    "under this load",
+        }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload)
         out["cpu_baseline"]["gpu_over_cpu_1core"] = value / out["cpu_baseline"]["value"]

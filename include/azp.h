@@ -29,8 +29,11 @@
  *   - per-type-pair tables (rcutsq, ronsq, params) are indexed
  *     type_i * ntypes + type_j and must be symmetric.
  *   - outputs are OVERWRITTEN for all N local particles.
- *   - all pointers prefixed d_ are device pointers borrowed for the call;
- *     the library allocates nothing and never synchronises the stream.
+ *   - all pointers prefixed d_ are device pointers borrowed for the call. The
+ *     bond, DPD, aniso, barrier, NVE, neighbor-list and generic pair kernels
+ *     allocate nothing and never synchronise the stream; azp_pair_plan_build and
+ *     the plan cache behind azp_pair_forces_* (see there) own device workspace
+ *     and synchronise.
  *   - every function returns 0 on success, a positive hipError_t value if the
  *     launch failed, or a negative azp_status for invalid arguments; nothing
  *     throws across this boundary.
@@ -111,6 +114,8 @@ void azp_quartic_params_unpack(const azp_quartic_params* p, double* k, double* r
 
 /* ---- pair forces ---- */
 
+#define AZP_PAIR_FLAG_NO_AUTO_PLAN 1u /* azp_pair_forces_*: always the generic kernel (no cached tile plan) */
+
 /* Mirrors hoomd::md::kernel::pair_args_t (minus charge and devprop). */
 typedef struct azp_pair_args
     {
@@ -132,7 +137,7 @@ typedef struct azp_pair_args
     uint32_t compute_virial;
     uint32_t block_size;         /* 0 = library default                             */
     uint32_t threads_per_particle; /* 0 = library heuristic; else 1,2,4,8,16,32     */
-    uint32_t _pad;
+    uint32_t flags;              /* AZP_PAIR_FLAG_*                                 */
     uint32_t range_first;        /* compute only particles [range_first, range_first + */
     uint32_t range_count;        /* range_count); range_count = 0 means all N. Lets a   */
                                  /* caller overlap the ghost exchange with the interior */
@@ -165,6 +170,17 @@ typedef struct azp_pair_args
                                     NeighborList::distanceCheck compares with r_buff / 2.    */
     } azp_pair_args;
 
+/* The five entry points below take what gpu_compute_pair_forces<E> takes and nothing
+ * else. With threads_per_particle == 0 (library's choice) they run the LDS-staged tile
+ * kernel from a plan that libazp compiles and caches by itself (csrc/pair_auto.hpp): each
+ * call fingerprints the list on the device (row lengths, row starts, cutoffs, box; the
+ * entries themselves for lists of up to 2^22 entries, sampled beyond), measures the
+ * largest displacement since the plan was compiled, reads the result (<= 24 KiB) back (ONE stream
+ * synchronisation per call) and recompiles the plan when the list changed. A caller that
+ * passes an explicit threads_per_particle (HOOMD's autotuner value), or sets
+ * AZP_PAIR_FLAG_NO_AUTO_PLAN, or runs with AZP_AUTO_PLAN=0 in the environment, gets the
+ * generic kernel, which never synchronises. Callers that know when the list changes use
+ * the azp_pair_plan_* API below instead and pay neither check nor readback. */
 int azp_pair_forces_perturbed_lennard_jones(const azp_pair_args* args, const azp_plj_params* d_params, void* stream);
 int azp_pair_forces_hertz(const azp_pair_args* args, const azp_hertz_params* d_params, void* stream);
 int azp_pair_forces_expanded_yukawa(const azp_pair_args* args, const azp_yukawa_params* d_params, void* stream);
@@ -211,6 +227,17 @@ int azp_pair_plan_build(azp_pair_plan* plan, const azp_pair_args* args, void* st
  * live for more than ~50 force calls; callers that rebuild more often turn it off. */
 int azp_pair_plan_set_bank_order(azp_pair_plan* plan, int enabled);
 int azp_pair_plan_query(const azp_pair_plan* plan, azp_pair_plan_info* info);
+
+/* The plan cache behind azp_pair_forces_* (diagnostics and tests). */
+typedef struct azp_auto_plan_stats
+    {
+    uint64_t calls;             /* calls that went through the cache                  */
+    uint64_t compiles;          /* plan compilations (list changed / first use)      */
+    uint64_t reuses;            /* calls served by an unchanged plan                 */
+    uint64_t generic_fallbacks; /* calls whose list could not be tiled               */
+    } azp_auto_plan_stats;
+void azp_pair_auto_plan_get_stats(azp_auto_plan_stats* out);
+void azp_pair_auto_plan_clear(void); /* frees every cached plan (synchronises the device) */
 
 int azp_pair_forces_planned_perturbed_lennard_jones(azp_pair_plan* plan, const azp_pair_args* args,
                                                     const azp_plj_params* d_params, void* stream);
@@ -353,6 +380,23 @@ int azp_nlist_distance_check(uint32_t n, const double* d_pos, const double* d_po
  * row_doubles doubles (4 for positions / velocities / orientations). The send buffer of
  * the per-step ghost exchange; replaces the pack half of HOOMD's CommunicatorGPU. */
 int azp_halo_pack(uint32_t n, const double* d_src, const int64_t* d_idx, uint32_t row_doubles, double* d_dst, void* stream);
+
+/* Several per-particle arrays in ONE send buffer (DPD: positions + velocities + tags; aniso:
+ * positions + orientations), so that a step needs a single collective. Packed row k holds, field
+ * after field and each starting on an 8-byte boundary, row d_idx[k] of every field's array;
+ * packed_row_bytes = sum of the fields' row sizes rounded up to 8. unpack writes packed row k to
+ * row k of each field's destination (the caller passes the address of its first ghost row). */
+#define AZP_HALO_MAX_FIELDS 4
+typedef struct azp_halo_field
+    {
+    void* d_data;       /* pack: the source array; unpack: the first destination row */
+    uint32_t row_bytes; /* bytes per particle, multiple of 4                         */
+    uint32_t _pad;
+    } azp_halo_field;
+int azp_halo_pack_fields(uint32_t n, uint32_t n_fields, const azp_halo_field* fields, const int64_t* d_idx, void* d_packed,
+                         uint32_t packed_row_bytes, void* stream);
+int azp_halo_unpack_fields(uint32_t n, uint32_t n_fields, const azp_halo_field* fields, const void* d_packed,
+                           uint32_t packed_row_bytes, void* stream);
 
 /* ---- one-body harmonic barriers ----
  * Replaces the reference's own kernel driver

@@ -31,7 +31,9 @@ def _dev(a, dtype=None):
     return torch.from_numpy(a).to("cuda:0")
 
 
-def gpu_pair_args(pos, box, nl, ntypes, r_cut, r_on, mode, virial, N=None, tpp=0, block_size=0, r_list_max=0.0):
+def gpu_pair_args(pos, box, nl, ntypes, r_cut, r_on, mode, virial, N=None, tpp=0, block_size=0, r_list_max=0.0, auto_plan=False):
+    """auto_plan=False: azp_pair_forces_* run the generic kernel (AZP_PAIR_FLAG_NO_AUTO_PLAN);
+    True: the HOOMD-signature call as the adapter makes it (plan cache inside libazp)."""
     import torch
 
     pos = np.ascontiguousarray(pos, dtype=np.float64)
@@ -65,6 +67,7 @@ def gpu_pair_args(pos, box, nl, ntypes, r_cut, r_on, mode, virial, N=None, tpp=0
     a.compute_virial = int(bool(virial))
     a.block_size = block_size
     a.threads_per_particle = tpp
+    a.flags = 0 if auto_plan else _lib.PAIR_FLAG_NO_AUTO_PLAN
     a.r_list_max = r_list_max
     return a, t
 
@@ -84,10 +87,11 @@ def _finish(t, virial):
 
 
 def gpu_pair_forces(name, pos, box, nl, params, r_cut, r_on=0.0, mode="none", ntypes=1, N=None, virial=False, tpp=0,
-                    block_size=0, r_list_max=0.0, planned=False, plan_info=None, r_inner=None):
+                    block_size=0, r_list_max=0.0, planned=False, plan_info=None, r_inner=None, auto_plan=False):
     """planned=True: build a tile plan from the list and use the *_planned entry
-    point; plan_info (a dict) receives azp_pair_plan_query's answer."""
-    a, t = gpu_pair_args(pos, box, nl, ntypes, r_cut, r_on, mode, virial, N, tpp, block_size, r_list_max)
+    point; plan_info (a dict) receives azp_pair_plan_query's answer. auto_plan=True: the
+    plain entry point with libazp's own plan cache (what the HOOMD adapter calls)."""
+    a, t = gpu_pair_args(pos, box, nl, ntypes, r_cut, r_on, mode, virial, N, tpp, block_size, r_list_max, auto_plan)
     p = _dev(np.atleast_2d(params).astype(np.float64))
     if r_inner is not None:  # plan row-ordering hint (azp_pair_args.d_rinnersq)
         ri = _dev(np.broadcast_to(np.asarray(r_inner, dtype=np.float64) ** 2, (ntypes, ntypes)).reshape(-1).copy())

@@ -846,3 +846,34 @@ def test_north_star_full_size_properties():
     total = f_whole[:, :3].sum(dim=0).abs().max()
     assert float(total) <= 1e-9 * scale
     assert abs(nl.n_pairs / n - 136.26) < 0.05
+
+
+def test_api_r_cut_and_mode_change_rebuild_list_and_plan(oracle):
+    """Changing r_cut (within and beyond the buffer) or the mode after the first compute:
+    HOOMD rebuilds the neighbor list when a consumer's r_cut matrix changes; here the list
+    and the tile plan (whose row classes were cut against the old r_cut) must follow, or
+    pairs between the old and the new cutoff are silently dropped."""
+    import azplugins_amd as azp
+
+    pos, L, _ = H.lattice_config(14, 1.1, 0.11, seed=33, ntypes=1)
+    p = PAIR_PARAMS["PerturbedLennardJones"](0, 0)
+    sim = azp.Simulation(device="cuda:0", seed=1)
+    sim.create_state_from_snapshot(azp.Snapshot.from_arrays(pos[:, :3], L))
+    nl = azp.nlist.Cell(buffer=0.3)
+    pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=2.0, mode="none")
+    pot.params[("A", "A")] = p
+    sim.operations.integrator = azp.Integrator(dt=0.001, forces=[pot])
+    sim.run(0)
+    box = oracle.make_box(L)
+    params = oracle.pack_pair_params("PerturbedLennardJones", p)
+    builds = nl.num_builds
+    for r_cut, mode in ((2.0, "none"), (2.2, "none"), (2.2, "shift"), (2.9, "shift"), (1.6, "xplor")):
+        pot.r_cut[("A", "A")] = r_cut
+        pot.mode = mode
+        pot.r_on[("A", "A")] = 0.8 * r_cut
+        pot.compute(0)
+        onl = oracle.build_nlist(pos, box, r_cut + 0.3, half=True)
+        f_ref = oracle.pair_forces("PerturbedLennardJones", pos, box, onl, params, r_cut, 0.8 * r_cut, mode, half=True)
+        assert_close(np.c_[pot.forces, pot.energies], f_ref, what="r_cut=%g mode=%s" % (r_cut, mode))
+        assert pot.plan_info["valid"] == 1
+    assert nl.num_builds >= builds + 3  # every r_cut change rebuilt the list

@@ -183,6 +183,16 @@ def test_external_barrier_host_logic(oracle):
     assert l.azp_spherical_barrier_valid(10.0, C.byref(box)) == 1
     assert l.azp_spherical_barrier_valid(10.1, C.byref(box)) == 0
     assert l.azp_spherical_barrier_valid(-0.1, C.byref(box)) == 0
+    # triclinic: makeCoordinates shears the corners, lo.y = -(Ly/2 + yz Lz/2) (HOOMD BoxDim), so
+    # the accepted range of H widens with yz > 0 and narrows with yz < 0
+    tri = _lib.make_box((20.0, 20.0, 10.0), tilt=(0.1, 0.0, 0.4))
+    assert l.azp_planar_barrier_valid(11.9, C.byref(tri)) == 1
+    assert l.azp_planar_barrier_valid(12.0, C.byref(tri)) == 0
+    assert l.azp_planar_barrier_valid(-12.0, C.byref(tri)) == 1
+    assert l.azp_planar_barrier_valid(-12.1, C.byref(tri)) == 0
+    tri = _lib.make_box((20.0, 20.0, 10.0), tilt=(0.0, 0.0, -0.4))
+    assert l.azp_planar_barrier_valid(7.9, C.byref(tri)) == 1
+    assert l.azp_planar_barrier_valid(8.0, C.byref(tri)) == 0
 
 
 def test_cpp_class_names_match_reference_module():
@@ -273,3 +283,12 @@ def test_synthetic_configs_shapes():
     c = syn.config_dpd(4096)
     assert c["vel"].shape == (4096, 3) and abs(c["vel"].var() - 1.0) < 0.1
     assert sorted(c["tag"].tolist()) == list(range(4096))
+
+
+def test_constant_volume_accepts_only_all_particles():
+    """The NVE kernels integrate all N particles: a filter other than All() is an
+    error, not silently ignored (hoomd.md.methods.ConstantVolume(filter=...))."""
+    assert isinstance(azp.ConstantVolume().filter, azp.All)
+    assert azp.ConstantVolume(filter=azp.All()).filter == azp.All()
+    with pytest.raises(azp.AzpError):
+        azp.ConstantVolume(filter=[0, 1, 2])
