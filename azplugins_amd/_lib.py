@@ -212,6 +212,8 @@ SYMBOLS = {
     "azp_pair_forces_planned_dpd_conservative": (C.c_int, [_VP, C.POINTER(PairArgs), _VP, _VP]),
     "azp_dpd_forces_general_weight": (C.c_int, [C.POINTER(DPDArgs), _VP, _VP]),
     "azp_aniso_forces_two_patch_morse": (C.c_int, [C.POINTER(AnisoArgs), _VP, _VP]),
+    "azp_dpd_forces_planned_general_weight": (C.c_int, [_VP, C.POINTER(DPDArgs), _VP, _VP]),
+    "azp_aniso_forces_planned_two_patch_morse": (C.c_int, [_VP, C.POINTER(AnisoArgs), _VP, _VP]),
     "azp_bond_forces_double_well": (C.c_int, [C.POINTER(BondArgs), _VP, _VP, _VP]),
     "azp_bond_forces_quartic": (C.c_int, [C.POINTER(BondArgs), _VP, _VP, _VP]),
     "azp_nlist_cell_assign": (C.c_int, [C.POINTER(NlistArgs), _VP]),

@@ -56,6 +56,7 @@ class Bond(Force):
 
         self._require()
         st = self._state
+        self._ensure_buffers()
         if self._tables is None:
             self._build_tables()
         tab = st.bond_table()

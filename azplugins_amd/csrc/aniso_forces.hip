@@ -8,7 +8,7 @@
 // quaternion (32 B) gathers; the patch director n = rotate(q, x^) of particle i
 // is computed once per particle, that of j once per pair. Outputs: force
 // (fx, fy, fz, e) and torque (tx, ty, tz, 0), both N x 4.
-#include "pair_kernel.hpp"
+#include "xtiled.hpp"
 
 namespace azp
 {
@@ -257,7 +257,129 @@ static int launch_aniso_tpp(const azp_aniso_args& args, const AnisoKArgs& k, con
     default: return AZP_ERROR_INVALID_ARGUMENT;
         }
     }
+
+// ---- tile-staged form (xtiled.hpp): the patch director n_j = rotate(q_j, x^) of every
+// staged particle is computed ONCE per tile and kept in LDS next to its position (the
+// reference rotates per pair, src/AnisoPairEvaluatorTwoPatchMorse.h:145-146); same per-pair
+// arithmetic as aniso_loop above ----
+struct XTPM
+    {
+    typedef azp_tpm_params Params;
+    typedef TPMCoeff Coeff;
+    struct KExtra
+        {
+        const double* orientation;
+        double* torque;
+        };
+    static constexpr int kExtra = 3; // n_j
+    static constexpr bool kTag = false;
+    struct Own
+        {
+        double3 n;
+        };
+    struct Acc
+        {
+        double f[3], t[3], pe;
+        };
+    static __device__ __forceinline__ Coeff prepare(const Params& p, double rcutsq, const KExtra&, uint32_t shift_mode)
+        {
+        return tpm_prepare(p, rcutsq, shift_mode == AZP_SHIFT_SHIFT);
+        }
+    static __device__ __forceinline__ void load_extra(const KExtra& x, uint32_t j, double (&e)[3], uint32_t&)
+        {
+        const double3 n = patch_director(load_scalar4(x.orientation, j));
+        e[0] = n.x; e[1] = n.y; e[2] = n.z;
+        }
+    static __device__ __forceinline__ void load_own(const KExtra& x, uint32_t idx, Own& o)
+        {
+        o.n = patch_director(load_scalar4(x.orientation, idx));
+        }
+    static __device__ __forceinline__ void zero(Acc& a)
+        {
+        a.f[0] = a.f[1] = a.f[2] = a.t[0] = a.t[1] = a.t[2] = a.pe = 0.0;
+        }
+    static __device__ __forceinline__ bool in_range(const Coeff& c, double rsq) { return !(rsq > c.rcutsq); } // (:135-136)
+    template<bool VIRIAL>
+    static __device__ __forceinline__ void pair(const Coeff& c, const KExtra&, const Own& o, double dx, double dy, double dz, double rsq,
+                                                const double (&nj)[3], uint32_t, Acc& a, double (&v)[6])
+        {
+        const double3 n_i = o.n;
+        const double3 n_j = make_double3(nj[0], nj[1], nj[2]);
+        const double rinv = 1.0 / sqrt(rsq);
+        const double r = 1.0 / rinv;
+        const double3 u = make_double3(dx * rinv, dy * rinv, dz * rinv);
+        double UMorse = -c.M_d;
+        double dUMorse_dr = 0.0;
+        if (r > c.r_eq || c.repulsion)
+            {
+            const double Morse_exp = exp(-(r - c.r_eq) * c.M_rinv);
+            const double one_minus_exp = 1.0 - Morse_exp;
+            UMorse = c.M_d * (one_minus_exp * one_minus_exp - 1.0);
+            dUMorse_dr = 2.0 * c.M_d * c.M_rinv * Morse_exp * one_minus_exp;
+            }
+        const double gamma_i = u.x * n_i.x + u.y * n_i.y + u.z * n_i.z;
+        const double gamma_i_exp = exp(-c.omega * (gamma_i * gamma_i - c.alpha));
+        const double Omega_i = 1.0 / (1.0 + gamma_i_exp);
+        const double gamma_j = u.x * n_j.x + u.y * n_j.y + u.z * n_j.z;
+        const double gamma_j_exp = exp(-c.omega * (gamma_j * gamma_j - c.alpha));
+        const double Omega_j = 1.0 / (1.0 + gamma_j_exp);
+        const double OO = Omega_i * Omega_j;
+        const double e = (UMorse - c.U_shift) * OO;
+        const double dU_dr = dUMorse_dr * OO;
+        const double dU_dgi = 2.0 * c.omega * gamma_i * gamma_i_exp * Omega_i * Omega_i * UMorse * Omega_j;
+        const double dU_dgj = 2.0 * c.omega * gamma_j * gamma_j_exp * Omega_j * Omega_j * UMorse * Omega_i;
+        const double3 rxni = cross3(u, n_i);
+        const double3 rxnj = cross3(u, n_j);
+        const double3 mu = make_double3(-u.x, -u.y, -u.z);
+        const double3 nip = cross3(mu, rxni);
+        const double3 njp = cross3(mu, rxnj);
+        const double Fx = -dU_dr * u.x - rinv * (dU_dgi * nip.x + dU_dgj * njp.x);
+        const double Fy = -dU_dr * u.y - rinv * (dU_dgi * nip.y + dU_dgj * njp.y);
+        const double Fz = -dU_dr * u.z - rinv * (dU_dgi * nip.z + dU_dgj * njp.z);
+        a.f[0] += Fx; a.f[1] += Fy; a.f[2] += Fz;
+        a.t[0] = __builtin_fma(dU_dgi, rxni.x, a.t[0]);
+        a.t[1] = __builtin_fma(dU_dgi, rxni.y, a.t[1]);
+        a.t[2] = __builtin_fma(dU_dgi, rxni.z, a.t[2]);
+        a.pe += e;
+        if (VIRIAL)
+            {
+            v[0] = __builtin_fma(dx, Fx, v[0]);
+            v[1] = __builtin_fma(dy, Fx, v[1]);
+            v[2] = __builtin_fma(dz, Fx, v[2]);
+            v[3] = __builtin_fma(dy, Fy, v[3]);
+            v[4] = __builtin_fma(dz, Fy, v[4]);
+            v[5] = __builtin_fma(dz, Fz, v[5]);
+            }
+        }
+    static __device__ __forceinline__ void store(const Acc& a, const PairKArgs& p, const KExtra& x, uint32_t idx)
+        {
+        store_scalar4(p.force, idx, a.f[0], a.f[1], a.f[2], 0.5 * a.pe);
+        store_scalar4(x.torque, idx, a.t[0], a.t[1], a.t[2], 0.0);
+        }
+    };
 } // namespace azp
+
+extern "C" int azp_aniso_forces_planned_two_patch_morse(azp_pair_plan* plan_, const azp_aniso_args* args, const azp_tpm_params* d_params,
+                                                        void* stream)
+    {
+    using namespace azp;
+    if (!plan_ || !args)
+        return AZP_ERROR_INVALID_ARGUMENT;
+    const int bad = validate_pair_args(&args->pair, d_params);
+    if (bad < 0) return bad;
+    if (bad > 0) return AZP_SUCCESS;
+    if (!args->d_orientation || !args->d_torque || args->pair.shift_mode == AZP_SHIFT_XPLOR)
+        return AZP_ERROR_INVALID_ARGUMENT; // HOOMD aniso pairs accept "none" / "shift"
+    const PairPlan& plan = *reinterpret_cast<const PairPlan*>(plan_);
+    if (plan.builds == 0 || plan.N != args->pair.N || plan.nlist_ptr != args->pair.d_nlist || plan.head_ptr != args->pair.d_head_list)
+        return AZP_ERROR_INVALID_ARGUMENT; // a plan compiled from a different list is a caller bug
+    if (!xtiled_usable(plan, args->pair))
+        return azp_aniso_forces_two_patch_morse(args, d_params, stream);
+    XTPM::KExtra x;
+    x.orientation = args->d_orientation;
+    x.torque = args->d_torque;
+    return launch_xtiled<XTPM>(plan, args->pair, x, d_params, static_cast<hipStream_t>(stream));
+    }
 
 extern "C" int azp_aniso_forces_two_patch_morse(const azp_aniso_args* args, const azp_tpm_params* d_params,
                                                 void* stream)

@@ -9,7 +9,7 @@
 // block per in-range pair, computed in registers, keyed by
 // (seed, timestep, min tag, max tag) so both owners of a pair draw the same
 // number (cross-rank consistency relies on this: :213-231).
-#include "pair_kernel.hpp"
+#include "xtiled.hpp"
 
 namespace azp
 {
@@ -220,7 +220,114 @@ static int launch_dpd_tpp(const azp_dpd_args& args, const DPDKArgs& k, const azp
     default: return AZP_ERROR_INVALID_ARGUMENT;
         }
     }
+
+// ---- tile-staged form (xtiled.hpp): positions, velocities and tags of a tile's neighbors
+// are staged once in LDS; same per-pair arithmetic as dpd_loop above ----
+struct XDPD
+    {
+    typedef azp_dpd_params Params;
+    typedef DPDCoeff Coeff;
+    struct KExtra
+        {
+        const double* vel;
+        const uint32_t* tag;
+        uint64_t timestep;
+        double deltaT, T;
+        uint32_t seed, _pad;
+        };
+    static constexpr int kExtra = 3; // vx, vy, vz
+    static constexpr bool kTag = true;
+    struct Own
+        {
+        double3 v;
+        uint32_t tag;
+        };
+    struct Acc
+        {
+        double fx, fy, fz, pe;
+        };
+    static __device__ __forceinline__ Coeff prepare(const Params& p, double rcutsq, const KExtra& x, uint32_t)
+        {
+        return dpd_prepare(p, rcutsq, x.deltaT, x.T);
+        }
+    static __device__ __forceinline__ void load_extra(const KExtra& x, uint32_t j, double (&e)[3], uint32_t& tag)
+        {
+        const double3 vj = load_scalar3_of4(x.vel, j);
+        e[0] = vj.x; e[1] = vj.y; e[2] = vj.z;
+        tag = x.tag[j];
+        }
+    static __device__ __forceinline__ void load_own(const KExtra& x, uint32_t idx, Own& o)
+        {
+        o.v = load_scalar3_of4(x.vel, idx);
+        o.tag = x.tag[idx];
+        }
+    static __device__ __forceinline__ void zero(Acc& a) { a.fx = a.fy = a.fz = a.pe = 0.0; }
+    static __device__ __forceinline__ bool in_range(const Coeff& c, double rsq) { return rsq < c.rcutsq; }
+    template<bool VIRIAL>
+    static __device__ __forceinline__ void pair(const Coeff& c, const KExtra& x, const Own& o, double dx, double dy, double dz, double rsq,
+                                                const double (&vj)[3], uint32_t tagj, Acc& a, double (&v)[6])
+        {
+        const double rdotv = dx * (o.v.x - vj[0]) + dy * (o.v.y - vj[1]) + dz * (o.v.z - vj[2]);
+        const double alpha = dpd_alpha((uint16_t)x.seed, o.tag, tagj, x.timestep);
+        const double rinv = 1.0 / sqrt(rsq);
+        const double r = 1.0 / rinv;
+        const double force_divr_cons = c.A * (rinv - c.rcutinv);
+        const double wR = weight_pow(1.0 - r * c.rcutinv, c.half_s) * rinv;
+        double force_divr = force_divr_cons - c.gamma * wR * wR * rdotv;
+        force_divr += c.noise * wR * alpha;
+        a.fx = __builtin_fma(dx, force_divr, a.fx);
+        a.fy = __builtin_fma(dy, force_divr, a.fy);
+        a.fz = __builtin_fma(dz, force_divr, a.fz);
+        a.pe += c.A * (c.rcut - r) - 0.5 * c.A * c.rcutinv * (c.rcutsq - rsq);
+        if (VIRIAL)
+            {
+            const double fxx = force_divr_cons * dx, fyy = force_divr_cons * dy;
+            v[0] = __builtin_fma(fxx, dx, v[0]);
+            v[1] = __builtin_fma(fxx, dy, v[1]);
+            v[2] = __builtin_fma(fxx, dz, v[2]);
+            v[3] = __builtin_fma(fyy, dy, v[3]);
+            v[4] = __builtin_fma(fyy, dz, v[4]);
+            v[5] = __builtin_fma(force_divr_cons * dz, dz, v[5]);
+            }
+        }
+    static __device__ __forceinline__ void store(const Acc& a, const PairKArgs& p, const KExtra&, uint32_t idx)
+        {
+        store_scalar4(p.force, idx, a.fx, a.fy, a.fz, 0.5 * a.pe);
+        }
+    };
 } // namespace azp
+
+static int azp_dpd_validate(const azp_dpd_args* args, const azp_dpd_params* d_params)
+    {
+    if (!args)
+        return AZP_ERROR_INVALID_ARGUMENT;
+    const int bad = azp::validate_pair_args(&args->pair, d_params);
+    if (bad != 0)
+        return bad;
+    if (!args->d_vel || !args->d_tag || args->pair.shift_mode != AZP_SHIFT_NONE)
+        return AZP_ERROR_INVALID_ARGUMENT; // DPD accepts mode "none" only (src/pair.py:215)
+    return 0;
+    }
+
+extern "C" int azp_dpd_forces_planned_general_weight(azp_pair_plan* plan_, const azp_dpd_args* args, const azp_dpd_params* d_params,
+                                                     void* stream)
+    {
+    using namespace azp;
+    if (!plan_)
+        return AZP_ERROR_INVALID_ARGUMENT;
+    const int bad = azp_dpd_validate(args, d_params);
+    if (bad < 0) return bad;
+    if (bad > 0) return AZP_SUCCESS;
+    const PairPlan& plan = *reinterpret_cast<const PairPlan*>(plan_);
+    if (plan.builds == 0 || plan.N != args->pair.N || plan.nlist_ptr != args->pair.d_nlist || plan.head_ptr != args->pair.d_head_list)
+        return AZP_ERROR_INVALID_ARGUMENT; // a plan compiled from a different list is a caller bug
+    if (!xtiled_usable(plan, args->pair))
+        return azp_dpd_forces_general_weight(args, d_params, stream);
+    XDPD::KExtra x;
+    x.vel = args->d_vel; x.tag = args->d_tag; x.timestep = args->timestep; x.deltaT = args->deltaT; x.T = args->T;
+    x.seed = args->seed; x._pad = 0;
+    return launch_xtiled<XDPD>(plan, args->pair, x, d_params, static_cast<hipStream_t>(stream));
+    }
 
 extern "C" int azp_dpd_forces_general_weight(const azp_dpd_args* args, const azp_dpd_params* d_params, void* stream)
     {

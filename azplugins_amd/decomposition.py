@@ -221,8 +221,13 @@ class HaloExchange:
             out.append((a2, buf))
         return out
 
-    def transfer(self, packed):
-        """all_to_all_single of the packed buffers straight into the ghost rows."""
+    def transfer(self, packed, state=None):
+        """all_to_all_single of the packed buffers straight into the ghost rows.
+        ``state``: the State whose arrays these are -- its position generation is bumped,
+        so that the neighbor list's distance check (and with it the displacement bound of
+        the tile kernel) sees the ghosts' new positions. Without it the caller vouches that
+        the ghosts did not move (a static benchmark); the run-time path is
+        azplugins_amd.domain.DeviceDomain, which Simulation.run drives."""
         import torch
         import torch.distributed as dist
 
@@ -242,11 +247,13 @@ class HaloExchange:
                                            input_split_sizes=self.send_splits, group=self.group)
             sent += buf.numel() * buf.element_size()
         self.bytes_sent_per_step = sent
+        if state is not None:
+            state.position_generation += 1
 
-    def exchange(self, *arrays):
+    def exchange(self, *arrays, state=None):
         """Each array is (N_local + n_ghost, w); rows [N_local:] are overwritten
         with the owners' current rows."""
-        self.transfer(self.pack(*arrays))
+        self.transfer(self.pack(*arrays), state=state)
 
 
 def build_rank_state(cfg, decomp, rank, device):
@@ -263,16 +270,42 @@ def build_rank_state(cfg, decomp, rank, device):
     return dom, state
 
 
+def rank_simulation(cfg, decomp, rank, device, seed=1):
+    """Simulation of one rank of a decomposed run: its local particles from a replicated
+    synthetic configuration (every rank regenerates it from the hash RNG), a DeviceDomain
+    that has selected its ghosts, and the State pointed at the domain's arrays."""
+    from .domain import DeviceDomain
+    from .simulation import Simulation
+    from .state import Snapshot
+
+    xyz = cfg["xyz"]
+    mine = np.flatnonzero(decomp.owner(xyz) == rank)
+    tag = cfg["tag"][mine] if "tag" in cfg else mine.astype(np.uint32)
+    snap = Snapshot.from_arrays(xyz[mine], cfg["L"], tag=tag, velocity=cfg["vel"][mine] if "vel" in cfg else None,
+                                orientation=cfg["orientation"][mine] if "orientation" in cfg else None)
+    sim = Simulation(device=device, seed=seed)
+    st = sim.create_state_from_snapshot(snap)
+    arrays = dict(pos=st.pos, vel=st.vel, orientation=st.orientation, tag=st.tag, image=st.image)
+    dom = DeviceDomain(decomp, rank, arrays, density=xyz.shape[0] / float(np.prod(decomp.L)))
+    dom.rebuild()
+    sim.attach_domain(dom)
+    return sim, dom
+
+
 def bench_main(args, rank, world, local_rank):
-    """bench.py for N > 1 GPUs.
+    """bench.py for N > 1 GPUs: --workload ns (PerturbedLJ, the north star), c4 (DPD
+    thermostat, BASELINE configs[3]: 2x2x2 over 8 GPUs) or c5 (TwoPatchMorse, configs[4]:
+    1x1x4 slabs over 4 GPUs).
 
-    Default: WEAK scaling -- every GPU holds the north-star load (2^20 particles,
-    FCC 64^3 cells per GPU, so the global box is the rank grid times that) and the
-    job-wide rate is N_global / step time. ``--scaling strong`` keeps the global
-    problem at N = 2^20 instead.
+    Default: STRONG scaling -- the workload's own N is cut into world sub-boxes (the north
+    star asks for >= 6x at 8 GPUs vs 1 at N = 2^20); ``--scaling weak`` (ns only) gives every
+    GPU 2^20 particles instead.
 
-    One step = pack ghost rows -> all_to_all_single (RCCL) on a side stream ->
-    interior forces (overlapping the exchange) -> boundary forces."""
+    One step = pack the ghost rows of every array the potential reads into ONE buffer ->
+    ONE all_to_all_single (RCCL) on a side stream -> interior forces (they list no ghost:
+    beside the exchange) -> boundary forces. The list is static (positions are not
+    integrated here), so the generation of the state is not bumped and the tile kernel keeps
+    displacement bound 0; Simulation.run does bump it after every exchange."""
     import json
     import os
     import time
@@ -299,30 +332,45 @@ def bench_main(args, rank, world, local_rank):
         dist.init_process_group(backend="nccl", device_id=torch.device(dev))
     else:
         dist.init_process_group(backend=backend)
-    weak = getattr(args, "scaling", "weak") == "weak" and args.workload == "ns"
+    weak = getattr(args, "scaling", "strong") == "weak" and args.workload == "ns"
+    grid = None
     if weak:
         grid = choose_grid(world, np.ones(3))
         cfg = syn.config_north_star(tuple(64 * g for g in grid))
+    elif args.workload == "c4":
+        cfg = syn.config_dpd()
+    elif args.workload == "c5":
+        cfg = syn.config_tpm()
     else:
-        grid = None
         cfg = make_workload(args.workload)
+    kind = {"DPDGeneralWeight": "dpd", "TwoPatchMorse": "tpm"}.get(cfg["potential"], "plj")
     N_global = cfg["xyz"].shape[0]
     r_ghost = cfg["r_cut"] + cfg["r_buff"]
     decomp = Decomposition(cfg["L"], world, r_ghost, grid=grid)
-    dom, state = build_rank_state(cfg, decomp, rank, dev)
-    halo = HaloExchange(dom, dev)
+    sim, dom = rank_simulation(cfg, decomp, rank, dev)
+    state = sim.state
 
-    sim = azp.Simulation(device=dev, seed=1)
-    sim.state = state
     nl = azp.nlist.Cell(buffer=cfg["r_buff"])
-    pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=cfg["r_cut"], mode=args.mode)
+    if kind == "dpd":
+        pot = azp.pair.DPDGeneralWeight(nlist=nl, kT=cfg["kT"], default_r_cut=cfg["r_cut"])
+        sim.seed = cfg["seed"]
+        dt = cfg["dt"]
+        extra = 4 * 8 + 4
+    elif kind == "tpm":
+        pot = azp.pair.TwoPatchMorse(nlist=nl, default_r_cut=cfg["r_cut"], mode="shift")
+        dt = 0.005
+        extra = 8 * 8
+    else:
+        pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=cfg["r_cut"], mode=args.mode)
+        dt = 0.005
+        extra = 0
     pot.params[("A", "A")] = cfg["params"]
     pot.threads_per_particle = args.tpp
     pot.block_size = args.block_size
     pot.use_plan = not args.no_plan
-    sim.operations.integrator = azp.Integrator(dt=0.005, forces=[pot])
-    halo.exchange(state.pos)
+    sim.operations.integrator = azp.Integrator(dt=dt, forces=[pot])
     sim.run(0)
+    halo_names = sim._halo_fields()
     mean_neigh = nl.n_pairs / max(dom.N_local, 1)
 
     main = torch.cuda.current_stream()
@@ -340,13 +388,12 @@ def bench_main(args, rank, world, local_rank):
         if overlap:
             comm.wait_stream(main)
             with torch.cuda.stream(comm):
-                packed = halo.pack(state.pos)   # gather the rows the peers need
-                halo.transfer(packed)           # ghost positions over RCCL/xGMI
+                dom.transfer(dom.pack(halo_names))  # ghost rows over RCCL/xGMI, one collective
             pot.compute(0, particle_range=(0, n_int))       # needs no ghost: runs beside pack + exchange
             main.wait_stream(comm)
             pot.compute(0, particle_range=(n_int, n_bnd))   # shell particles
         else:
-            halo.transfer(halo.pack(state.pos))
+            dom.exchange(halo_names)
             pot.compute(0)
 
     for _ in range(args.warmup):
@@ -384,37 +431,47 @@ def bench_main(args, rank, world, local_rank):
 
     verify = None
     if os.environ.get("AZP_BENCH_VERIFY") == "1":
-        # rehearsal check: the decomposed forces against one single-domain evaluation of
-        # the whole system on rank 0's GPU (files under the temp dir, keyed by global id)
+        # rehearsal check: the decomposed forces (and torques) against one single-domain
+        # evaluation of the whole system on rank 0's GPU (files under the temp dir, keyed by tag)
         import tempfile
 
         tmp = os.path.join(tempfile.gettempdir(), "azp_verify_%s" % os.environ.get("MASTER_PORT", "0"))
         os.makedirs(tmp, exist_ok=True)
         pot.compute(0)
-        np.savez(os.path.join(tmp, "rank%d.npz" % rank), gid=dom.local_gid, force=pot.force_tensor.cpu().numpy())
+        np.savez(os.path.join(tmp, "rank%d.npz" % rank), tag=state.tag[: dom.N_local].cpu().numpy().view(np.uint32),
+                 force=pot.force_tensor.cpu().numpy(), torque=pot.torque_tensor.cpu().numpy())
         dist.barrier()
         if rank == 0:
-            sim1 = azp.Simulation(device=dev, seed=1)
-            sim1.create_state_from_snapshot(azp.Snapshot.from_arrays(cfg["xyz"], cfg["L"]))
+            sim1 = azp.Simulation(device=dev, seed=sim.seed)
+            sim1.create_state_from_snapshot(azp.Snapshot.from_arrays(
+                cfg["xyz"], cfg["L"], tag=cfg.get("tag"), velocity=cfg.get("vel"), orientation=cfg.get("orientation")))
             nl1 = azp.nlist.Cell(buffer=cfg["r_buff"])
-            pot1 = azp.pair.PerturbedLennardJones(nlist=nl1, default_r_cut=cfg["r_cut"], mode=args.mode)
+            if kind == "dpd":
+                pot1 = azp.pair.DPDGeneralWeight(nlist=nl1, kT=cfg["kT"], default_r_cut=cfg["r_cut"])
+            elif kind == "tpm":
+                pot1 = azp.pair.TwoPatchMorse(nlist=nl1, default_r_cut=cfg["r_cut"], mode="shift")
+            else:
+                pot1 = azp.pair.PerturbedLennardJones(nlist=nl1, default_r_cut=cfg["r_cut"], mode=args.mode)
             pot1.params[("A", "A")] = cfg["params"]
-            sim1.operations.integrator = azp.Integrator(dt=0.005, forces=[pot1])
+            sim1.operations.integrator = azp.Integrator(dt=dt, forces=[pot1])
             sim1.run(0)
-            ref = pot1.force_tensor.cpu().numpy()
+            tag1 = sim1.state.tag.cpu().numpy().view(np.uint32).astype(np.int64)
+            ref = np.zeros((N_global, 8))
+            ref[tag1] = np.c_[pot1.force_tensor.cpu().numpy(), pot1.torque_tensor.cpu().numpy()]
             got = np.full_like(ref, np.nan)
             for r in range(world):
                 d = np.load(os.path.join(tmp, "rank%d.npz" % r))
-                got[d["gid"]] = d["force"]
+                got[d["tag"].astype(np.int64)] = np.c_[d["force"], d["torque"]]
             verify = float(np.abs(got - ref).max() / np.abs(ref).max())
             del sim1, pot1, nl1
         dist.barrier()
 
     if rank == 0:
-        b_alg = alg_bytes_per_particle(mean_neigh)
+        b_alg = alg_bytes_per_particle(mean_neigh, extra=extra)
         achieved = b_alg * dom.N_local / (kernel_ms * 1e-3) / 1e9
+        names = {"plj": "PerturbedLennardJones pair force", "dpd": "DPD GeneralWeight thermostat force", "tpm": "TwoPatchMorse pair force"}
         out = {
-            "metric": "particle-steps/sec, PerturbedLennardJones pair force",
+            "metric": "particle-steps/sec, %s" % names[kind],
             "value": N_global * args.steps / wall_max,
             "unit": "particle-steps/s",
             "n_gpus": world,
@@ -427,17 +484,17 @@ def bench_main(args, rank, world, local_rank):
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "%s: PerturbedLennardJones N=%d global (%s: %d per GPU) rho*=0.8 r_cut=%.1f buffer=%.1f mode=%s, "
-                            "spatial decomposition %dx%dx%d, ghost positions exchanged every step "
-                            "(one all_to_all_single over RCCL into the ghost rows%s)"
-                            % ((cfg["name"], N_global, "weak scaling" if weak else "strong scaling", N_global // world,
-                                cfg["r_cut"], cfg["r_buff"], args.mode) + decomp.grid
-                               + (", overlapped with the interior forces" if overlap else "",)),
+                "workload": "%s: %s N=%d global (%s: %d per GPU) r_cut=%.1f buffer=%.1f, spatial decomposition %dx%dx%d, ghost rows of "
+                            "%s exchanged every step (one all_to_all_single over RCCL%s); static list (bench.py --gpus 1 times an MD "
+                            "rebuild cycle instead)"
+                            % ((cfg["name"], cfg["potential"], N_global, "weak scaling" if weak else "strong scaling", N_global // world,
+                                cfg["r_cut"], cfg["r_buff"]) + decomp.grid
+                               + (" + ".join(halo_names), ", overlapped with the interior forces" if overlap else "")),
                 "N": N_global,
                 "mean_neighbors": mean_neigh,
                 "parallelism": "dd%d" % world,
                 "per_rank": [dict(N_local=int(g[0]), n_ghost=int(g[1]), n_interior=int(g[2])) for g in gathered],
-                "halo_bytes_sent_per_step_rank0": halo.bytes_sent_per_step,
+                "halo_bytes_sent_per_step_rank0": dom.bytes_sent_per_step,
                 "max_rel_error_vs_single_domain": verify,
                 "launch": azp._lib.last_launch(),
                 "tile_plan": pot.plan_info,
@@ -445,7 +502,7 @@ def bench_main(args, rank, world, local_rank):
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
-                "traffic": None, "kernel": "pair force kernel(s) of one step on rank 0 (interior + boundary launch), all local particles",
+                "traffic": None, "kernel": "force kernel(s) of one step on rank 0 (interior + boundary launch), all local particles",
                 "kernel_ms": kernel_ms, "algorithmic_bytes_per_particle": b_alg,
             },
         }

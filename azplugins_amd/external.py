@@ -39,6 +39,7 @@ class HarmonicBarrier(Force):
 
         self._require()
         st = self._state
+        self._ensure_buffers()
         if self._tables is None:
             raw = np.zeros((len(st.types), 2))
             for i, t in enumerate(st.types):

@@ -150,6 +150,18 @@ class Force:
         if not self._attached:
             raise _lib.AzpError("%s is not attached to a simulation; call sim.run(0) first" % type(self).__name__)
 
+    def _ensure_buffers(self):
+        """Result buffers follow the number of local particles (it changes when particles
+        migrate between the ranks of a decomposed run)."""
+        import torch
+
+        N = self._state.N
+        if self._force.shape[0] != N:
+            dev = self._state.device
+            self._force = torch.zeros((N, 4), dtype=torch.float64, device=dev)
+            self._torque = torch.zeros((N, 4), dtype=torch.float64, device=dev)
+            self._virial = torch.zeros((6, N), dtype=torch.float64, device=dev)
+
     def compute(self, timestep=None):
         self._require()
         raise NotImplementedError

@@ -32,6 +32,11 @@ class NeighborList:
         self.single_pass = True
         self._consumer_version = 0        # bumped when a consumer's r_cut matrix changes
         self._built_consumer_version = None
+        # domain-decomposed runs (azplugins_amd.domain): the rebuild decision is collective
+        # (reduce_flag: bool -> bool, an all-reduce over the ranks) and particles migrate /
+        # ghosts are re-selected before the list is rebuilt (before_rebuild(state))
+        self.reduce_flag = None
+        self.before_rebuild = None
 
     # -- consumers (pair potentials) register their r_cut matrices ---------
     def _add_consumer(self, force):
@@ -74,9 +79,14 @@ class Cell(NeighborList):
         if not force and self.nlist is not None:
             if self._built_generation == state.position_generation:
                 return
-            if not self._moved_too_far(state):
+            moved = self._moved_too_far(state)
+            if self.reduce_flag is not None:
+                moved = bool(self.reduce_flag(moved))
+            if not moved:
                 self._built_generation = state.position_generation
                 return
+            if self.before_rebuild is not None:
+                self.before_rebuild(state)
         self._build(state)
         self._built_generation = state.position_generation
 

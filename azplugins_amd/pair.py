@@ -27,6 +27,7 @@ class Pair(Force):
     _schema = {}
     _param_doubles = 4              # size of the raw param struct in doubles
     _accepted_modes = ("none", "shift", "xplor")
+    _halo_fields = ("pos",)         # per-particle arrays whose ghost rows the kernel reads (decomposed runs)
 
     def __init__(self, nlist, default_r_cut=None, default_r_on=0.0, mode="none"):
         super().__init__()
@@ -184,6 +185,7 @@ class Pair(Force):
         self._require()
         st = self._state
         self.nlist.compute(st)
+        self._ensure_buffers()  # after the list: a rebuild of a decomposed run migrates particles
         if self._tables is None:
             self._build_tables()
         stream = torch.cuda.current_stream(st.device).cuda_stream
@@ -192,33 +194,46 @@ class Pair(Force):
         self._range = None
         self._computed_generation = st.position_generation
 
+    def _prepare_plan(self, a, stream):
+        """Compile the tile plan when the neighbor list was rebuilt since the last compile and
+        fill in the displacement fields of ``a`` for this launch."""
+        if self._plan is None:
+            self._plan = _lib.PairPlan()
+        key = (id(self.nlist), self.nlist.num_builds, self.threads_per_particle)
+        if self._plan_builds != key:
+            # recompile the plan only when the neighbor list was rebuilt
+            first, count = a.range_first, a.range_count
+            a.range_first = a.range_count = 0
+            # bank-aware rows pay off only for lists that live long (include/azp.h): keep them
+            # for the first build and whenever the previous list served >= 50 force calls
+            calls = getattr(self, "_calls_since_plan", None)
+            self._plan.set_bank_order((calls is None or calls >= 50) if self.plan_bank_order is None else self.plan_bank_order)
+            self._calls_since_plan = 0
+            self._plan.build(a, stream)
+            a.range_first, a.range_count = first, count
+            self._plan_builds = key
+            self._plan_disp0 = self.nlist.displacement_bound(self._state)
+            # this launch sees exactly the positions the plan was built from
+            a.has_displacement_bound, a.displacement_bound = (1 if self.use_displacement_bound else 0), 0.0
+        self._calls_since_plan = getattr(self, "_calls_since_plan", 0) + 1
+
+    def _wrap_args(self, a, timestep):
+        """The argument struct of this potential's entry points around the common pair args."""
+        return a
+
     def _launch(self, stream, timestep):
         a = self._pair_args()
-        if self.use_plan and self._planned_entry is not None:
-            if self._plan is None:
-                self._plan = _lib.PairPlan()
-            key = (id(self.nlist), self.nlist.num_builds, self.threads_per_particle)
-            if self._plan_builds != key:
-                # recompile the plan only when the neighbor list was rebuilt
-                first, count = a.range_first, a.range_count
-                a.range_first = a.range_count = 0
-                # bank-aware rows pay off only for lists that live long (include/azp.h): keep them
-                # for the first build and whenever the previous list served >= 50 force calls
-                calls = getattr(self, "_calls_since_plan", None)
-                self._plan.set_bank_order((calls is None or calls >= 50) if self.plan_bank_order is None else self.plan_bank_order)
-                self._calls_since_plan = 0
-                self._plan.build(a, stream)
-                a.range_first, a.range_count = first, count
-                self._plan_builds = key
-                self._plan_disp0 = self.nlist.displacement_bound(self._state)
-                # this launch sees exactly the positions the plan was built from
-                a.has_displacement_bound, a.displacement_bound = (1 if self.use_displacement_bound else 0), 0.0
-            self._calls_since_plan = getattr(self, "_calls_since_plan", 0) + 1
+        planned = self.use_plan and self._planned_entry is not None
+        if planned:
+            self._prepare_plan(a, stream)
+        args = self._wrap_args(a, timestep)
+        params = self._tables["params"].data_ptr()
+        if planned:
             fn = getattr(_lib.lib(), self._planned_entry)
-            _lib.check(fn(self._plan.handle, C.byref(a), self._tables["params"].data_ptr(), stream), self._planned_entry)
+            _lib.check(fn(self._plan.handle, C.byref(args), params, stream), self._planned_entry)
             return
         fn = getattr(_lib.lib(), self._entry)
-        _lib.check(fn(C.byref(a), self._tables["params"].data_ptr(), stream), self._entry)
+        _lib.check(fn(C.byref(args), params, stream), self._entry)
 
     @property
     def plan_info(self):
@@ -309,7 +324,9 @@ class DPDGeneralWeight(Pair):
     timestep (HOOMD ``Variant``). ``mode`` is always ``"none"``."""
 
     _cpp_class_name = "PotentialPairDPDThermoGeneralWeight"
+    _halo_fields = ("pos", "vel")   # (ghost tags change only when the ghosts are re-selected)
     _entry = "azp_dpd_forces_general_weight"
+    _planned_entry = "azp_dpd_forces_planned_general_weight"
     _schema = dict(A=float, gamma=float, s=float)
     _accepted_modes = ("none",)
 
@@ -328,10 +345,10 @@ class DPDGeneralWeight(Pair):
         sim._warn_if_seed_unset()
         super()._attach(sim)
 
-    def _launch(self, stream, timestep):
+    def _wrap_args(self, a, timestep):
         st = self._state
         d = _lib.DPDArgs()
-        d.pair = self._pair_args()
+        d.pair = a
         d.d_vel = st.vel.data_ptr()
         d.d_tag = st.tag.data_ptr()
         ts = self._sim.timestep if timestep is None else timestep
@@ -339,8 +356,7 @@ class DPDGeneralWeight(Pair):
         d.deltaT = float(self._sim.dt)
         d.T = float(self.kT(ts)) if callable(self.kT) else float(self.kT)
         d.seed = int(self._sim.seed) & 0xFFFF
-        _lib.check(_lib.lib().azp_dpd_forces_general_weight(C.byref(d), self._tables["params"].data_ptr(), stream),
-                   self._entry)
+        return d
 
 
 class DPDConservativeGeneralWeight(Pair):
@@ -367,7 +383,9 @@ class TwoPatchMorse(Pair):
     ``"none"`` / ``"shift"``)."""
 
     _cpp_class_name = "AnisoPotentialPairTwoPatchMorse"
+    _halo_fields = ("pos", "orientation")
     _entry = "azp_aniso_forces_two_patch_morse"
+    _planned_entry = "azp_aniso_forces_planned_two_patch_morse"
     _schema = dict(M_d=float, M_r=float, r_eq=float, omega=float, alpha=float, repulsion=bool)
     _param_doubles = 6
     _accepted_modes = ("none", "shift")
@@ -388,14 +406,13 @@ class TwoPatchMorse(Pair):
         return dict(M_d=v[0].value, M_r=v[1].value, r_eq=v[2].value, omega=v[3].value, alpha=v[4].value,
                     repulsion=bool(rep.value))
 
-    def _launch(self, stream, timestep):
+    def _wrap_args(self, a, timestep):
         st = self._state
         g = _lib.AnisoArgs()
-        g.pair = self._pair_args()
+        g.pair = a
         g.d_orientation = st.orientation.data_ptr()
         g.d_torque = self._torque.data_ptr()
-        _lib.check(_lib.lib().azp_aniso_forces_two_patch_morse(C.byref(g), self._tables["params"].data_ptr(), stream),
-                   self._entry)
+        return g
 
 
 __all__ = ["Colloid", "DPDGeneralWeight", "DPDConservativeGeneralWeight", "ExpandedYukawa", "Hertz",

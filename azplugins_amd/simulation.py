@@ -63,6 +63,39 @@ class Simulation:
         self.timestep = 0
         self.operations = _Operations()
         self._attached = []
+        self.domain = None  # azplugins_amd.domain.DeviceDomain of a decomposed run (attach_domain)
+
+    def attach_domain(self, domain):
+        """Domain-decomposed run: ``domain`` (a rebuilt ``DeviceDomain``) owns the particle
+        arrays. Every step the ghost rows of the arrays the forces read are exchanged; when
+        any rank's distance check asks for a neighbor-list rebuild, all ranks migrate their
+        particles and re-select their ghosts first (HOOMD: Communicator::migrateParticles /
+        exchangeGhosts ahead of NeighborList::compute)."""
+        self.domain = domain
+        domain.attach_state(self.state)
+        self.operations.tuners.clear()  # the domain keeps its own interior | boundary | ghost order
+
+    def _halo_fields(self):
+        names = ["pos"]
+        for f in self.operations.integrator.forces:
+            for n in getattr(f, "_halo_fields", ()):
+                if n not in names and n in self.domain.names:
+                    names.append(n)
+        return names
+
+    def _wire_domain(self):
+        """Point the neighbor lists of the attached forces at the domain's collective hooks."""
+        dom = self.domain
+
+        def before_rebuild(state):
+            dom.rebuild()
+            dom.attach_state(state)
+
+        for f in self.operations.integrator.forces:
+            nl = getattr(f, "nlist", None)
+            if nl is not None:
+                nl.reduce_flag = dom.all_reduce_flag
+                nl.before_rebuild = before_rebuild
 
     def _warn_if_seed_unset(self):
         if self.seed is None:
@@ -114,6 +147,8 @@ class Simulation:
         self._attach_all()
         integ = self.operations.integrator
         st = self.state
+        if self.domain is not None:
+            self._wire_domain()
         self._compute_forces()
         if steps == 0 or not integ.methods:
             return
@@ -122,19 +157,25 @@ class Simulation:
         import ctypes as C
 
         a = _lib.NVEArgs()
-        a.d_pos = st.pos.data_ptr()
-        a.d_vel = st.vel.data_ptr()
-        a.d_net_force = st.net_force.data_ptr()
-        a.d_image = st.image.data_ptr()
         a.box = st.box.to_c()
         a.dt = integ.dt
-        a.N = st.N
         lib = _lib.lib()
         stream = torch.cuda.current_stream(st.device).cuda_stream
+
+        def point_at_state():
+            # (the arrays are replaced when particles migrate between ranks or are re-sorted)
+            a.d_pos = st.pos.data_ptr()
+            a.d_vel = st.vel.data_ptr()
+            a.d_net_force = st.net_force.data_ptr()
+            a.d_image = st.image.data_ptr()
+            a.N = st.N
+
         for _ in range(steps):
             # velocity Verlet (libazp kernels): v += a dt/2, x += v dt, wrap | forces | v += a dt/2
-            a.d_net_force = st.net_force.data_ptr()
+            point_at_state()
             _lib.check(lib.azp_integrate_nve_step_one(C.byref(a), stream), "azp_integrate_nve_step_one")
+            if self.domain is not None:
+                self.domain.exchange(self._halo_fields())  # ghost rows follow their owners' particles
             st.position_generation += 1
             self.timestep += 1
             # re-index the particles between the position update and the force
@@ -144,7 +185,7 @@ class Simulation:
                 if tuner.trigger_period > 0 and self.timestep % tuner.trigger_period == 0 and st.n_ghost == 0:
                     tuner.sort(self)
             self._compute_forces()
-            a.d_net_force = st.net_force.data_ptr()
+            point_at_state()
             _lib.check(lib.azp_integrate_nve_step_two(C.byref(a), stream), "azp_integrate_nve_step_two")
 
     def kinetic_temperature(self):

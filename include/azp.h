@@ -264,6 +264,11 @@ typedef struct azp_dpd_args
     } azp_dpd_args;
 
 int azp_dpd_forces_general_weight(const azp_dpd_args* args, const azp_dpd_params* d_params, void* stream);
+/* Tile-staged form: positions, velocities and tags of a tile's neighbors staged once in LDS
+ * (csrc/xtiled.hpp); `plan` is compiled from args->pair with azp_pair_plan_build. Falls back to
+ * the kernel above when the list cannot be tiled. */
+int azp_dpd_forces_planned_general_weight(azp_pair_plan* plan, const azp_dpd_args* args, const azp_dpd_params* d_params,
+                                          void* stream);
 
 /* Mirrors hoomd::md::kernel::a_pair_args_t. */
 typedef struct azp_aniso_args
@@ -274,6 +279,10 @@ typedef struct azp_aniso_args
     } azp_aniso_args;
 
 int azp_aniso_forces_two_patch_morse(const azp_aniso_args* args, const azp_tpm_params* d_params, void* stream);
+/* Tile-staged form: the patch director of every staged neighbor is computed once per tile
+ * and kept in LDS with its position (csrc/xtiled.hpp). */
+int azp_aniso_forces_planned_two_patch_morse(azp_pair_plan* plan, const azp_aniso_args* args, const azp_tpm_params* d_params,
+                                             void* stream);
 
 /* ---- bond forces ---- */
 

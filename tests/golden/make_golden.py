@@ -10,6 +10,11 @@
   {shift off, on}) of (force_divr, pair_eng) from the oracle's scalar
   evaluators, including the branch edges (r ~ r_wca, r_cut, r_eq, r_0).
 
+* c3_sample.npz, c4_sample.npz, c5_sample.npz -- BASELINE.json configs[2..4] at full
+  size (N = 1,048,576 / 2,097,152 / 524,288): forces (and torques) of every
+  (N / 1024)-th particle plus sums over all particles, from the oracle
+  (`python tests/golden/make_golden.py full`, a few minutes of CPU).
+
 The oracle itself is pinned by the reference's known-answer cases
 (reference_cases.json); these fixtures freeze its output so that a later change
 to the oracle cannot silently move the target.
@@ -81,7 +86,80 @@ def sweeps():
     np.savez_compressed(os.path.join(HERE, "sweeps.npz"), **out)
 
 
+N_SAMPLE = 1024
+
+
+def _sample_and_sums(n, *arrays):
+    """Every (n / 1024)-th particle in full precision, plus sums over ALL particles: the
+    plain sum and the sum of absolute values of every column (SURVEY 8c golden item 4)."""
+    idx = (np.arange(N_SAMPLE, dtype=np.int64) * n) // N_SAMPLE
+    out = dict(sample_index=idx)
+    for k, a in enumerate(arrays):
+        out["sample_%d" % k] = a[idx]
+        out["sum_%d" % k] = a.sum(axis=0)
+        out["abssum_%d" % k] = np.abs(a).sum(axis=0)
+    return out
+
+
+def c3_c4_c5():
+    """BASELINE.json configs[2..4] at full size from the oracle (HOOMD-style loops, all
+    cores): C3 = PerturbedLJ (mode shift) with bonded exclusions + DoubleWell bonds,
+    N = 1,048,576; C4 = DPD thermostat N = 2,097,152 (seed 7, timestep 0); C5 =
+    TwoPatchMorse N = 524,288 (mode shift): 1,024-particle samples + checksums."""
+    nt = os.cpu_count() or 8
+    # ---- C3
+    cfg = syn.config_chains()
+    pos = syn.pos4(cfg["xyz"])
+    n = pos.shape[0]
+    box = oracle.make_box(cfg["L"])
+    n_excl = np.zeros(n, dtype=np.uint32)
+    excl = np.zeros((n, 2), dtype=np.uint32)
+    b = cfg["bonds"].astype(np.int64)
+    for me, other in ((b[:, 0], b[:, 1]), (b[:, 1], b[:, 0])):
+        order = np.argsort(me, kind="stable")
+        m, o = me[order], other[order]
+        first = np.r_[True, m[1:] != m[:-1]]
+        rank = np.arange(m.size) - np.maximum.accumulate(np.where(first, np.arange(m.size), 0))
+        excl[m, n_excl[m] + rank] = o
+        np.add.at(n_excl, m, 1)
+    nl = oracle.build_nlist(pos, box, cfg["r_cut"] + cfg["r_buff"], exclusions=(n_excl, excl))
+    f_pair = oracle.pair_forces("PerturbedLennardJones", pos, box, nl, oracle.pack_pair_params("PerturbedLennardJones", cfg["params"]),
+                                cfg["r_cut"], mode="shift", nthreads=nt)
+    f_bond, bad = oracle.bond_forces("DoubleWell", pos, box, cfg["bonds"], np.zeros(len(cfg["bonds"]), dtype=np.uint32),
+                                     oracle.pack_bond_params("DoubleWell", cfg["bond_params"]))
+    assert bad == 0
+    np.savez_compressed(os.path.join(HERE, "c3_sample.npz"), mean_neighbors=nl[0].mean(), **_sample_and_sums(n, f_pair, f_bond))
+    del nl
+    # ---- C4
+    cfg = syn.config_dpd()
+    pos = syn.pos4(cfg["xyz"])
+    n = pos.shape[0]
+    vel = np.zeros((n, 4))
+    vel[:, :3] = cfg["vel"]
+    vel[:, 3] = 1.0
+    box = oracle.make_box(cfg["L"])
+    nl = oracle.build_nlist(pos, box, cfg["r_cut"] + cfg["r_buff"], half=True)
+    f = oracle.dpd_forces(pos, vel, cfg["tag"], box, nl, oracle.pack_pair_params("DPDGeneralWeight", cfg["params"]), cfg["r_cut"],
+                          cfg["kT"], cfg["dt"], cfg["seed"], 0, half=True)
+    np.savez_compressed(os.path.join(HERE, "c4_sample.npz"), mean_neighbors=2.0 * nl[0].mean(), **_sample_and_sums(n, f))
+    del nl
+    # ---- C5
+    cfg = syn.config_tpm()
+    pos = syn.pos4(cfg["xyz"])
+    n = pos.shape[0]
+    box = oracle.make_box(cfg["L"])
+    nl = oracle.build_nlist(pos, box, cfg["r_cut"] + cfg["r_buff"], half=True)
+    f, t = oracle.aniso_forces_tpm(pos, cfg["orientation"], box, nl, oracle.pack_pair_params("TwoPatchMorse", cfg["params"]),
+                                   cfg["r_cut"], mode="shift", half=True)
+    np.savez_compressed(os.path.join(HERE, "c5_sample.npz"), mean_neighbors=2.0 * nl[0].mean(), **_sample_and_sums(n, f, t))
+
+
 if __name__ == "__main__":
-    c1()
-    sweeps()
+    which = sys.argv[1:] or ["c1", "sweeps", "full"]
+    if "c1" in which:
+        c1()
+    if "sweeps" in which:
+        sweeps()
+    if "full" in which:
+        c3_c4_c5()
     print("golden fixtures written to", HERE)

@@ -111,9 +111,24 @@ def gpu_pair_forces(name, pos, box, nl, params, r_cut, r_on=0.0, mode="none", nt
     return _finish(t, virial)
 
 
+def _planned_call(entry, a, args_struct, p, plan_info):
+    """Build a tile plan from the list in ``a`` and call a *_planned entry point."""
+    plan = _lib.PairPlan()
+    plan.build(a, _stream())
+    if plan_info is not None:
+        plan_info.update(plan.info())
+    _lib.check(getattr(_lib.lib(), entry)(plan.handle, C.byref(args_struct), p.data_ptr(), _stream()), entry)
+    import torch
+
+    torch.cuda.synchronize()
+    del plan
+
+
 def gpu_dpd_forces(pos, vel, tag, box, nl, params, r_cut, kT, dt, seed, timestep, ntypes=1, N=None, virial=False,
-                   tpp=0, r_list_max=0.0):
+                   tpp=0, r_list_max=0.0, planned=False, plan_info=None, displacement_bound=None):
     a, t = gpu_pair_args(pos, box, nl, ntypes, r_cut, 0.0, "none", virial, N, tpp, 0, r_list_max)
+    if displacement_bound is not None:
+        a.has_displacement_bound, a.displacement_bound = 1, displacement_bound
     p = _dev(np.atleast_2d(params).astype(np.float64))
     v = _dev(vel, np.float64)
     tg = _dev(tag, np.uint32)
@@ -125,15 +140,20 @@ def gpu_dpd_forces(pos, vel, tag, box, nl, params, r_cut, kT, dt, seed, timestep
     d.deltaT = dt
     d.T = kT
     d.seed = seed
-    _lib.check(_lib.lib().azp_dpd_forces_general_weight(C.byref(d), p.data_ptr(), _stream()), "dpd")
+    if planned:
+        _planned_call("azp_dpd_forces_planned_general_weight", d.pair, d, p, plan_info)
+    else:
+        _lib.check(_lib.lib().azp_dpd_forces_general_weight(C.byref(d), p.data_ptr(), _stream()), "dpd")
     return _finish(t, virial)
 
 
 def gpu_aniso_forces(pos, orientation, box, nl, params, r_cut, mode="none", ntypes=1, N=None, virial=False, tpp=0,
-                     r_list_max=0.0):
+                     r_list_max=0.0, planned=False, plan_info=None, displacement_bound=None):
     import torch
 
     a, t = gpu_pair_args(pos, box, nl, ntypes, r_cut, 0.0, mode, virial, N, tpp, 0, r_list_max)
+    if displacement_bound is not None:
+        a.has_displacement_bound, a.displacement_bound = 1, displacement_bound
     p = _dev(np.atleast_2d(params).astype(np.float64))
     q = _dev(orientation, np.float64)
     tq = torch.full((a.N, 4), float("nan"), dtype=torch.float64, device="cuda:0")
@@ -141,7 +161,10 @@ def gpu_aniso_forces(pos, orientation, box, nl, params, r_cut, mode="none", ntyp
     g.pair = a
     g.d_orientation = q.data_ptr()
     g.d_torque = tq.data_ptr()
-    _lib.check(_lib.lib().azp_aniso_forces_two_patch_morse(C.byref(g), p.data_ptr(), _stream()), "aniso")
+    if planned:
+        _planned_call("azp_aniso_forces_planned_two_patch_morse", g.pair, g, p, plan_info)
+    else:
+        _lib.check(_lib.lib().azp_aniso_forces_two_patch_morse(C.byref(g), p.data_ptr(), _stream()), "aniso")
     out = _finish(t, virial)
     torque = tq.cpu().numpy()
     return (out[0], torque, out[1]) if virial else (out, torque)

@@ -877,3 +877,109 @@ def test_api_r_cut_and_mode_change_rebuild_list_and_plan(oracle):
         assert_close(np.c_[pot.forces, pot.energies], f_ref, what="r_cut=%g mode=%s" % (r_cut, mode))
         assert pot.plan_info["valid"] == 1
     assert nl.num_builds >= builds + 3  # every r_cut change rebuilt the list
+
+
+@pytest.mark.parametrize("T", [1, 2])
+def test_planned_dpd_parity(oracle, T):
+    """Tile-staged DPD thermostat kernel (azp_dpd_forces_planned_general_weight: positions,
+    velocities and tags staged in LDS) against the oracle with the same Philox stream, with
+    and without the r_list_max hint, virial included; and with particles moved after the
+    plan was built (displacement bound: rows stop before the buffer shells that cannot have
+    come into range -- exact)."""
+    cfg = syn.config_dpd(6000)
+    n = cfg["xyz"].shape[0]
+    typeid = (np.arange(n) % T) if T > 1 else None
+    pos = syn.pos4(cfg["xyz"], typeid)
+    vel = np.zeros((n, 4))
+    vel[:, :3] = cfg["vel"]
+    vel[:, 3] = 1.0
+    box = oracle.make_box(cfg["L"])
+    tab = H.sym_table(T, lambda i, j: dict(A=25.0 - 5 * (i + j), gamma=4.5 + i + j, s=[0.5, 1.0, 2.0][i + j]))
+    params = np.array([oracle.pack_pair_params("DPDGeneralWeight", tab[i][j]) for i in range(T) for j in range(T)])
+    r_cut = np.full((T, T), 1.0)
+    if T > 1:
+        r_cut[0, 1] = r_cut[1, 0] = 0.9
+    nl_f = oracle.build_nlist(pos, box, r_cut + 0.4, ntypes=T)
+    kw = dict(kT=1.0, dt=0.01, seed=7, timestep=424242, ntypes=T)
+    f_ref, v_ref = oracle.dpd_forces(pos, vel, cfg["tag"], box, nl_f, params, r_cut, virial=True, **kw)
+    for hint in (0.0, 1.0 + 2 * 0.4):
+        info = {}
+        f_gpu, v_gpu = H.gpu_dpd_forces(pos, vel, cfg["tag"], (cfg["L"],), nl_f, params, r_cut, virial=True, planned=True, plan_info=info,
+                                        r_list_max=hint, **kw)
+        assert info["valid"] == 1
+        assert_close(f_gpu, f_ref, what="planned dpd force")
+        assert_close(v_gpu, v_ref, what="planned dpd virial")
+        assert_per_particle(f_gpu, f_ref)
+    # bound 0: every buffer entry skipped, same answer
+    f0 = H.gpu_dpd_forces(pos, vel, cfg["tag"], (cfg["L"],), nl_f, params, r_cut, planned=True, r_list_max=1.8, displacement_bound=0.0, **kw)
+    assert_close(f0, f_ref, what="planned dpd bound 0")
+
+
+def test_planned_dpd_after_particles_moved(oracle):
+    import ctypes as C
+
+    import torch
+
+    from azplugins_amd import _lib
+
+    cfg = syn.config_dpd(6000)
+    n = cfg["xyz"].shape[0]
+    pos0 = syn.pos4(cfg["xyz"])
+    vel = np.zeros((n, 4))
+    vel[:, :3] = cfg["vel"]
+    vel[:, 3] = 1.0
+    box = oracle.make_box(cfg["L"])
+    params = np.atleast_2d(oracle.pack_pair_params("DPDGeneralWeight", cfg["params"]))
+    r_buff = 0.4
+    nl = oracle.build_nlist(pos0, box, 1.0 + r_buff)
+    a, t = H.gpu_pair_args(pos0, (cfg["L"],), nl, 1, 1.0, 0.0, "none", False, r_list_max=1.0 + 2 * r_buff)
+    p = H._dev(params)
+    v = H._dev(vel)
+    tg = H._dev(cfg["tag"], np.uint32)
+    plan = _lib.PairPlan()
+    plan.build(a, H._stream())
+    assert plan.info()["valid"] == 1
+    tag = np.arange(n, dtype=np.uint64)
+    for frac in (0.0, 0.3, 0.7, 0.99):
+        d = np.stack([syn.normal(5, tag, c) for c in range(3)], axis=1)
+        amp = frac * 0.5 * r_buff
+        d *= (amp / np.linalg.norm(d, axis=1))[:, None]  # every particle sits ON the bound
+        moved = pos0.copy()
+        moved[:, :3] = syn.wrap(pos0[:, :3] + d, cfg["L"])
+        t["pos"].copy_(torch.from_numpy(moved))
+        f_ref = oracle.dpd_forces(moved, vel, cfg["tag"], box, nl, params, 1.0, 1.0, 0.01, 7, 99)
+        for known, bound in ((0, 0.0), (1, amp * (1 + 1e-12))):
+            a.has_displacement_bound, a.displacement_bound = known, bound
+            dd = _lib.DPDArgs()
+            dd.pair = a
+            dd.d_vel, dd.d_tag = v.data_ptr(), tg.data_ptr()
+            dd.timestep, dd.deltaT, dd.T, dd.seed = 99, 0.01, 1.0, 7
+            t["force"].fill_(float("nan"))
+            _lib.check(_lib.lib().azp_dpd_forces_planned_general_weight(plan.handle, C.byref(dd), p.data_ptr(), H._stream()), "planned dpd")
+            torch.cuda.synchronize()
+            assert_close(t["force"].cpu().numpy(), f_ref, what="frac %g known %d" % (frac, known))
+
+
+@pytest.mark.parametrize("T,mode", [(1, "none"), (1, "shift"), (2, "shift")])
+def test_planned_aniso_parity(oracle, T, mode):
+    """Tile-staged TwoPatchMorse kernel (patch directors of the staged neighbors computed once
+    per tile): forces, torques, energies, virial against the oracle."""
+    cfg = syn.config_tpm(12, 12, 16)
+    n = cfg["xyz"].shape[0]
+    typeid = (np.arange(n) % T) if T > 1 else None
+    pos = syn.pos4(cfg["xyz"], typeid)
+    box = oracle.make_box(cfg["L"])
+    tab = H.sym_table(T, lambda i, j: dict(cfg["params"], M_d=1.8341 + 0.2 * (i + j), repulsion=bool((i + j) % 2)))
+    params = np.array([oracle.pack_pair_params("TwoPatchMorse", tab[i][j]) for i in range(T) for j in range(T)])
+    nl_f = oracle.build_nlist(pos, box, 2.0, ntypes=T)
+    f_ref, t_ref, v_ref = oracle.aniso_forces_tpm(pos, cfg["orientation"], box, nl_f, params, 1.6, mode, ntypes=T, virial=True)
+    for hint, bound in ((0.0, None), (1.6 + 0.8, None), (1.6 + 0.8, 0.0)):
+        info = {}
+        f_gpu, t_gpu, v_gpu = H.gpu_aniso_forces(pos, cfg["orientation"], (cfg["L"],), nl_f, params, 1.6, mode, ntypes=T, virial=True,
+                                                 planned=True, plan_info=info, r_list_max=hint, displacement_bound=bound)
+        assert info["valid"] == 1
+        assert_close(f_gpu[:, :3], f_ref[:, :3], what="planned aniso force")
+        assert_close(f_gpu[:, 3], f_ref[:, 3], what="planned aniso energy")
+        assert_close(t_gpu[:, :3], t_ref[:, :3], what="planned aniso torque")
+        assert_close(v_gpu, v_ref, what="planned aniso virial")
+        assert not t_gpu[:, 3].any()
