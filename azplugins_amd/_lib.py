@@ -261,6 +261,24 @@ def lib():
     return _lib
 
 
+_ext = None
+
+
+def ext_module():
+    """The compiled ``_azplugins`` module (pybind11, built by ``make -C csrc``): the class
+    names the reference registers (src/module.cc:110-166), holding the host-side parameter
+    tables in C++. libazp (and with it torch's HIP runtime) is loaded first."""
+    global _ext
+    if _ext is None:
+        lib()
+        try:
+            from . import _azplugins as m
+        except ImportError as e:
+            raise AzpError("the _azplugins extension module is missing (%s): build it with `make -C %s`" % (e, CSRC))
+        _ext = m
+    return _ext
+
+
 def check(rc, what="libazp call"):
     if rc != 0:
         msg = lib().azp_status_string(rc).decode()

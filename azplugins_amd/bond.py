@@ -28,27 +28,41 @@ class Bond(Force):
         self._computed_generation = None
 
     def _readback(self, key):
+        """After attaching, ``params[...]`` returns what the C++ object holds (HOOMD:
+        getParams -> asDict; src/pytest/test_bond.py:223)."""
         if not self._attached or key not in self.params._data:
             return None
-        return self._unpack(self._pack(self.params._data[key]))
+        self._sync_cpp()
+        return dict(self._cpp.getParams(key))
 
     def _attach(self, sim):
         import torch
 
         super()._attach(sim)
         self._tables = None
+        self._cpp = None
         self._flags = torch.zeros(1, dtype=torch.int32, device=self._state.device)
+
+    def _sync_cpp(self):
+        """The ``_azplugins`` C++ object (class name + "GPU") with the current parameters."""
+        types = list(self._state.bond_types) or ["A-A"]
+        if getattr(self, "_cpp", None) is None:
+            self._cpp = getattr(_lib.ext_module(), self._cpp_class_name + "GPU")(types)
+        for t in self._state.bond_types:
+            d = self.params.get_raw(t)
+            if d is not None:
+                self._cpp.setParams(t, d)
 
     def _build_tables(self):
         import torch
 
         types = self._state.bond_types
-        raw = np.zeros((max(len(types), 1), self._param_doubles))
-        for i, t in enumerate(types):
-            d = self.params.get_raw(t)
-            if d is None:
+        for t in types:
+            if self.params.get_raw(t) is None:
                 raise _lib.AzpError("%s.params[%r] is not set" % (type(self).__name__, t))
-            raw[i] = self._pack(d)
+        self._sync_cpp()
+        raw = np.frombuffer(self._cpp.params_bytes(), dtype=np.float64).reshape(max(len(types), 1), -1).copy()
+        assert raw.shape[1] == self._param_doubles
         self._tables = dict(params=torch.from_numpy(raw).to(self._state.device))
 
     def compute(self, timestep=None):

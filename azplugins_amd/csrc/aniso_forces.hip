@@ -273,6 +273,7 @@ struct XTPM
         };
     static constexpr int kExtra = 3; // n_j
     static constexpr bool kTag = false;
+    static constexpr int kMinWaves = 3; // 48 B per slot: three workgroups per CU at 1,024 slots, <= 168 VGPRs
     struct Own
         {
         double3 n;

@@ -237,6 +237,7 @@ struct XDPD
         };
     static constexpr int kExtra = 3; // vx, vy, vz
     static constexpr bool kTag = true;
+    static constexpr int kMinWaves = 2; // 52 B per slot: two workgroups per CU at 1,536 slots (80 KiB of LDS each)
     struct Own
         {
         double3 v;

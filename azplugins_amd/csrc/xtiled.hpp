@@ -19,6 +19,8 @@
 // the payload and the arithmetic.
 #pragma once
 
+#include <type_traits>
+
 #include "pair_tiled.hpp"
 
 namespace azp
@@ -30,7 +32,7 @@ template<class X, bool SINGLE> __host__ __device__ constexpr size_t xtiled_lds_s
     }
 
 template<class X, int CAP, bool VIRIAL, bool SINGLE>
-__global__ void __launch_bounds__(256, 2) xtiled_kernel(const TiledKArgs a, const typename X::KExtra x, const typename X::Params* __restrict__ params)
+__global__ void __launch_bounds__(256, X::kMinWaves) xtiled_kernel(const TiledKArgs a, const typename X::KExtra x, const typename X::Params* __restrict__ params)
     {
     typedef typename X::Coeff Coeff;
     constexpr int NE = X::kExtra; // extra doubles per slot
@@ -75,30 +77,53 @@ __global__ void __launch_bounds__(256, 2) xtiled_kernel(const TiledKArgs a, cons
     const bool active = idx < a.p.end;
     const bool no_hint = !(a.p.r_list_max > 0.0);
     bool lane_wide = a.p.box.triclinic;
-    for (uint32_t sidx = tid; sidx < n_stage; sidx += 256)
-        {
-        const uint32_t j = stage[sidx];
-        const double4 pj = load_scalar4(a.p.pos, j);
-        double ext[NE];
-        uint32_t tagj = 0;
-        X::load_extra(x, j, ext, tagj);
-        double px = pj.x, py = pj.y, pz = pj.z;
-        if (!a.p.box.triclinic)
-            {
-            if (a.p.box.px) px = __builtin_fma(-a.p.box.Lx, rint((px - c.x) * a.p.box.Lxinv), px);
-            if (a.p.box.py) py = __builtin_fma(-a.p.box.Ly, rint((py - c.y) * a.p.box.Lyinv), py);
-            if (a.p.box.pz) pz = __builtin_fma(-a.p.box.Lz, rint((pz - c.z) * a.p.box.Lzinv), pz);
-            if (no_hint)
-                lane_wide = lane_wide || (a.p.box.px && fabs(px - c.x) >= 0.25 * a.p.box.Lx) || (a.p.box.py && fabs(py - c.y) >= 0.25 * a.p.box.Ly)
-                            || (a.p.box.pz && fabs(pz - c.z) >= 0.25 * a.p.box.Lz);
-            }
-        s_pos[sidx + 1] = px; s_pos[CAP + sidx + 1] = py; s_pos[2 * CAP + sidx + 1] = pz;
+    // all loads of the staging are issued before the first result is used: the index loads of
+    // every round, then every position / payload load (two dependent round trips per tile)
+    __builtin_amdgcn_s_setprio(3); // a new tile shares its SIMDs with waves deep in the pair loop
+    {
+    constexpr int ROUNDS = (CAP + 255) / 256;
+    uint32_t sj[ROUNDS];
 #pragma unroll
-        for (int e = 0; e < NE; ++e)
-            s_ext[e * CAP + sidx + 1] = ext[e];
-        if (X::kTag) s_tag[sidx + 1] = tagj;
-        if (!SINGLE) s_type[sidx + 1] = type_from_w(pj.w);
+    for (int r = 0; r < ROUNDS; ++r)
+        {
+        const uint32_t sidx = (uint32_t)r * 256u + tid;
+        sj[r] = (sidx < n_stage) ? stage[sidx] : first;
         }
+    double4 pj[ROUNDS];
+    double ext[ROUNDS][NE];
+    uint32_t tagj[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r)
+        {
+        pj[r] = load_scalar4(a.p.pos, sj[r]);
+        tagj[r] = 0;
+        X::load_extra(x, sj[r], ext[r], tagj[r]);
+        }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r)
+        {
+        const uint32_t sidx = (uint32_t)r * 256u + tid;
+        if (sidx < n_stage)
+            {
+            double px = pj[r].x, py = pj[r].y, pz = pj[r].z;
+            if (!a.p.box.triclinic)
+                {
+                if (a.p.box.px) px = __builtin_fma(-a.p.box.Lx, rint((px - c.x) * a.p.box.Lxinv), px);
+                if (a.p.box.py) py = __builtin_fma(-a.p.box.Ly, rint((py - c.y) * a.p.box.Lyinv), py);
+                if (a.p.box.pz) pz = __builtin_fma(-a.p.box.Lz, rint((pz - c.z) * a.p.box.Lzinv), pz);
+                if (no_hint)
+                    lane_wide = lane_wide || (a.p.box.px && fabs(px - c.x) >= 0.25 * a.p.box.Lx)
+                                || (a.p.box.py && fabs(py - c.y) >= 0.25 * a.p.box.Ly) || (a.p.box.pz && fabs(pz - c.z) >= 0.25 * a.p.box.Lz);
+                }
+            s_pos[sidx + 1] = px; s_pos[CAP + sidx + 1] = py; s_pos[2 * CAP + sidx + 1] = pz;
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+                s_ext[e * CAP + sidx + 1] = ext[r][e];
+            if (X::kTag) s_tag[sidx + 1] = tagj[r];
+            if (!SINGLE) s_type[sidx + 1] = type_from_w(pj[r].w);
+            }
+        }
+    }
 
     // ---- this lane's particle, in the same image frame ----
     double3 pi = make_double3(0.0, 0.0, 0.0);
@@ -123,6 +148,7 @@ __global__ void __launch_bounds__(256, 2) xtiled_kernel(const TiledKArgs a, cons
         typei = type_from_w(p.w);
         }
     const bool wide = __syncthreads_or(lane_wide); // also publishes the staged tile
+    __builtin_amdgcn_s_setprio(0);
 
     const uint32_t slice = tile * 4 + wave;
     const uint32_t K = to_uniform(a.n_shells >= PLAN_SHELLS ? a.slice_K[slice] : a.slice_Kend[(PLAN_SHELLS + 1) * slice + a.n_shells]);
@@ -139,51 +165,64 @@ __global__ void __launch_bounds__(256, 2) xtiled_kernel(const TiledKArgs a, cons
         for (uint32_t t = 0; t < a.p.ntypes * a.p.ntypes; ++t)
             rcutsq_max = fmax(rcutsq_max, a.p.rcutsq[t]);
 
-    uint4 u = (K > 0) ? rows[0] : make_uint4(0, 0, 0, 0);
-    for (uint32_t kk = 0; kk < K; ++kk)
+#if defined(AZP_XTILED_ABLATE) && AZP_XTILED_ABLATE == 1
+    const uint32_t Kloop = 0; // ablation: staging only
+#else
+    const uint32_t Kloop = K;
+#endif
+    auto walk = [&](auto wide_tag)
         {
-        const uint4 un = rows[(uint64_t)((kk + 1 < K) ? kk + 1 : kk) * 64u]; // next chunk in flight
-        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-        uint32_t slot[8];
-        double dx[8], dy[8], dz[8], rsq[8];
-        bool any_in = false;
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
+        constexpr bool WIDE = decltype(wide_tag)::value;
+        uint4 u = (Kloop > 0) ? rows[0] : make_uint4(0, 0, 0, 0);
+        for (uint32_t kk = 0; kk < Kloop; ++kk)
             {
-            slot[e] = ((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu)) >> 3; // byte offset / 8
-            dx[e] = pi.x - s_pos[slot[e]];
-            dy[e] = pi.y - s_pos[CAP + slot[e]];
-            dz[e] = pi.z - s_pos[2 * CAP + slot[e]];
-            if (wide)
-                min_image(a.p.box, dx[e], dy[e], dz[e]);
-            rsq[e] = __builtin_fma(dz[e], dz[e], __builtin_fma(dy[e], dy[e], dx[e] * dx[e]));
-            if (wide)
-                rsq[e] = (slot[e] == 0) ? 1.0e60 : rsq[e]; // the minimum image would fold the padding slot back into the box
-            any_in = any_in || !(rsq[e] > rcutsq_max);
-            }
-        if (__any(any_in))
-            {
+            const uint4 un = rows[(uint64_t)((kk + 1 < Kloop) ? kk + 1 : kk) * 64u]; // next chunk in flight
+            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+            uint32_t slot[8];
+            double dx[8], dy[8], dz[8], rsq[8];
+            bool any_in = false;
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 {
-                Coeff cc;
-                if (SINGLE)
-                    cc = c0;
-                else
-                    cc = s_coeff[(uint32_t)typei * a.p.ntypes + (uint32_t)s_type[slot[e]]];
-                if (X::in_range(cc, rsq[e]) && slot[e] != 0)
-                    {
-                    double ext[NE];
+                slot[e] = ((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu)) >> 3; // byte offset / 8
+                dx[e] = pi.x - s_pos[slot[e]];
+                dy[e] = pi.y - s_pos[CAP + slot[e]];
+                dz[e] = pi.z - s_pos[2 * CAP + slot[e]];
+                if (WIDE)
+                    min_image(a.p.box, dx[e], dy[e], dz[e]);
+                rsq[e] = __builtin_fma(dz[e], dz[e], __builtin_fma(dy[e], dy[e], dx[e] * dx[e]));
+                if (WIDE)
+                    rsq[e] = (slot[e] == 0) ? 1.0e60 : rsq[e]; // the minimum image would fold the padding slot back into the box
+                any_in = any_in || !(rsq[e] > rcutsq_max);
+                }
+            if (__any(any_in))
+                {
 #pragma unroll
-                    for (int q = 0; q < NE; ++q)
-                        ext[q] = s_ext[q * CAP + slot[e]];
-                    const uint32_t tagj = X::kTag ? s_tag[slot[e]] : 0u;
-                    X::template pair<VIRIAL>(cc, x, own, dx[e], dy[e], dz[e], rsq[e], ext, tagj, acc, v);
+                for (int e = 0; e < 8; ++e)
+                    {
+                    Coeff cc;
+                    if (SINGLE)
+                        cc = c0;
+                    else
+                        cc = s_coeff[(uint32_t)typei * a.p.ntypes + (uint32_t)s_type[slot[e]]];
+                    if (X::in_range(cc, rsq[e]))
+                        {
+                        double ext[NE];
+#pragma unroll
+                        for (int q = 0; q < NE; ++q)
+                            ext[q] = s_ext[q * CAP + slot[e]];
+                        const uint32_t tagj = X::kTag ? s_tag[slot[e]] : 0u;
+                        X::template pair<VIRIAL>(cc, x, own, dx[e], dy[e], dz[e], rsq[e], ext, tagj, acc, v);
+                        }
                     }
                 }
+            u = un;
             }
-        u = un;
-        }
+        };
+    if (wide)
+        walk(std::true_type());
+    else
+        walk(std::false_type());
     if (active)
         {
         X::store(acc, a.p, x, idx);
@@ -255,8 +294,8 @@ int launch_xtiled_cap(const PairPlan& plan, const azp_pair_args& args, const typ
     switch (cap)
         {
     case 1024: return launch_xtiled_instance<X, 1024, VIRIAL, SINGLE>(plan, args, x, d_params, s);
-    case 1536:
-    case 1664: return launch_xtiled_instance<X, 1664, VIRIAL, SINGLE>(plan, args, x, d_params, s);
+    case 1536: return launch_xtiled_instance<X, 1536, VIRIAL, SINGLE>(plan, args, x, d_params, s);
+    case 1664:
     case 2048: return launch_xtiled_instance<X, 2048, VIRIAL, SINGLE>(plan, args, x, d_params, s);
     case 2560: return launch_xtiled_instance<X, 2560, VIRIAL, SINGLE>(plan, args, x, d_params, s);
     default: return AZP_ERROR_INVALID_ARGUMENT;

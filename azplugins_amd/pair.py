@@ -46,6 +46,8 @@ class Pair(Force):
         self._plan = None
         self._plan_builds = None
         self._tables = None
+        self._cpp = None            # the _azplugins C++ object (created on attach)
+        self._cpp_synced = False
         nlist._add_consumer(self)
 
     # -- mode ----------------------------------------------------------------
@@ -62,6 +64,7 @@ class Pair(Force):
 
     def _mark_dirty(self):
         self._tables = None
+        self._cpp_synced = False
         self._computed_generation = None
         # the tile plan orders and classifies rows against the cutoffs / inner radii it was
         # built with: recompile it with the new tables
@@ -81,12 +84,39 @@ class Pair(Force):
         raise NotImplementedError
 
     def _readback(self, key):
-        """After attaching, ``params[...]`` returns what the C side holds
+        """After attaching, ``params[...]`` returns what the C++ side holds
         (HOOMD: getParams -> asDict), as the reference tests check
         (src/pytest/test_pair.py:349)."""
         if not self._attached or key not in self.params._data:
             return None
-        return self._unpack(self._pack(self.params._data[key]))
+        self._sync_cpp()
+        return dict(self._cpp.getParams(*key))
+
+    def _make_cpp(self):
+        """The ``_azplugins`` class of this potential for a GPU device: ``_cpp_class_name +
+        "GPU"`` (hoomd's _attach_hook; the conservative DPD potential only has a CPU class)."""
+        ext = _lib.ext_module()
+        cls = getattr(ext, self._cpp_class_name + "GPU", None) or getattr(ext, self._cpp_class_name)
+        return cls(list(self._state.types))
+
+    def _sync_cpp(self):
+        """Push the Python-side type parameters into the C++ object (setParams / setRCut /
+        setROn / mode), as HOOMD's TypeParameter machinery does on attach and on every change."""
+        if self._cpp is None:
+            self._cpp = self._make_cpp()
+            self._cpp_synced = False
+        if self._cpp_synced:
+            return
+        types = self._state.types
+        for i, a in enumerate(types):
+            for b in types[i:]:
+                d = self.params.get_raw((a, b))
+                if d is not None:
+                    self._cpp.setParams(a, b, d)
+                self._cpp.setRCut(a, b, self.r_cut[(a, b)])
+                self._cpp.setROn(a, b, self.r_on[(a, b)])
+        self._cpp.mode = self._mode
+        self._cpp_synced = True
 
     def _types(self):
         return self._state.types if self._attached else None
@@ -104,23 +134,24 @@ class Pair(Force):
     def _attach(self, sim):
         super()._attach(sim)
         self._tables = None
+        self._cpp = None
+        self._cpp_synced = False
 
     def _build_tables(self):
+        """Device tables from the C++ object's host tables (param_type structs, r_cut^2, r_on^2)."""
         import torch
 
         types = self._state.types
         T = len(types)
-        raw = np.zeros((T * T, self._param_doubles))
-        rc = np.zeros(T * T)
-        ro = np.zeros(T * T)
-        for i, a in enumerate(types):
-            for j, b in enumerate(types):
-                d = self.params.get_raw((a, b))
-                if d is None:
+        for a in types:
+            for b in types:
+                if self.params.get_raw((a, b)) is None:
                     raise _lib.AzpError("%s.params[(%r, %r)] is not set" % (type(self).__name__, a, b))
-                raw[i * T + j] = self._pack(d)
-                rc[i * T + j] = self.r_cut[(a, b)] ** 2
-                ro[i * T + j] = self.r_on[(a, b)] ** 2
+        self._sync_cpp()
+        raw = np.frombuffer(self._cpp.params_bytes(), dtype=np.float64).reshape(T * T, -1).copy()
+        assert raw.shape[1] == self._param_doubles
+        rc = np.asarray(self._cpp.rcutsq())
+        ro = np.asarray(self._cpp.ronsq())
         dev = self._state.device
         self._tables = dict(
             params=torch.from_numpy(raw).to(dev), rcutsq=torch.from_numpy(rc).to(dev), ronsq=torch.from_numpy(ro).to(dev)

@@ -292,3 +292,74 @@ def test_constant_volume_accepts_only_all_particles():
     assert azp.ConstantVolume(filter=azp.All()).filter == azp.All()
     with pytest.raises(azp.AzpError):
         azp.ConstantVolume(filter=[0, 1, 2])
+
+
+def test_azplugins_extension_module_classes_and_dict_round_trip(oracle):
+    """The compiled _azplugins module (pybind11, HOOMD-free): exactly the class names the
+    reference registers for the force path (src/module.cc:114-164: base name on the CPU,
+    + "GPU" under ENABLE_HIP) and the C++ dict -> param_type -> dict round trip, which the
+    reference asserts with == after attaching (src/pytest/test_pair.py:349,
+    src/pytest/test_bond.py:223) for sigma = 1.05, 0.5, 0.85, 1.0."""
+    m = _lib.ext_module()
+    names = {n for n in dir(m) if "Potential" in n}
+    base = ["AnisoPotentialPairTwoPatchMorse", "PotentialPairColloid", "PotentialPairExpandedYukawa", "PotentialPairHertz",
+            "PotentialPairPerturbedLennardJones", "PotentialPairDPDThermoGeneralWeight", "PotentialBondDoubleWell",
+            "PotentialBondQuartic"]
+    assert names == set(base) | {b + "GPU" for b in base} | {"PotentialPairConservativeGeneralWeight"}
+    assert m.PotentialPairHertzGPU.on_gpu and not m.PotentialPairHertz.on_gpu
+    # param_type sizes (byte-compatible with the reference's structs)
+    assert [getattr(m, n).param_size for n in ("PotentialPairPerturbedLennardJones", "PotentialPairHertz", "PotentialPairExpandedYukawa",
+                                               "PotentialPairColloid", "PotentialPairDPDThermoGeneralWeight",
+                                               "AnisoPotentialPairTwoPatchMorse", "PotentialBondDoubleWell", "PotentialBondQuartic")] \
+        == [32, 8, 32, 32, 32, 48, 32, 64]
+    plj = m.PotentialPairPerturbedLennardJonesGPU(["A", "B"])
+    for sigma in (1.05, 0.5, 0.85, 1.0):  # the values of the reference's test cases
+        d = dict(epsilon=2.0, sigma=sigma, attraction_scale_factor=0.5)
+        plj.setParams("A", "B", d)
+        assert plj.getParams("A", "B") == d and plj.getParams("B", "A") == d  # exact, both orderings
+    assert not plj.hasParams("A", "A") and plj.hasParams("B", "A")
+    raw = np.frombuffer(plj.params_bytes(), dtype=np.float64).reshape(4, 4)
+    assert np.array_equal(raw[1], oracle.pack_pair_params("PerturbedLennardJones", d)) and np.array_equal(raw[1], raw[2])
+    assert not raw[0].any()
+    plj.setRCut("A", "B", 3.0)
+    plj.setROn("B", "A", 2.0)
+    assert plj.getRCut("B", "A") == 3.0 and plj.rcutsq() == [0.0, 9.0, 9.0, 0.0] and plj.ronsq()[1] == 4.0
+    plj.mode = "xplor"
+    assert plj.mode == "xplor" and plj.shift_mode == 2
+    with pytest.raises(RuntimeError):
+        plj.mode = "bogus"
+    with pytest.raises(RuntimeError):
+        plj.setParams("A", "C", d)  # unknown type
+    with pytest.raises(KeyError):
+        plj.setParams("A", "A", dict(epsilon=1.0, sigma=1.0))  # missing key, as the reference's dict constructor
+    cases = [
+        ("PotentialPairColloid", dict(A=100.0, a_1=1.5, a_2=0.75, sigma=1.05)),
+        ("PotentialPairExpandedYukawa", dict(epsilon=1.0, kappa=3.0, delta=1.0)),
+        ("PotentialPairHertz", dict(epsilon=2.0)),
+        ("PotentialPairDPDThermoGeneralWeight", dict(A=25.0, gamma=4.5, s=0.5)),
+        ("PotentialPairConservativeGeneralWeight", dict(A=2.0, gamma=4.5, s=2.0)),
+        ("AnisoPotentialPairTwoPatchMorse", dict(M_d=1.8341, M_r=0.0302, r_eq=1.0043, omega=5.0, alpha=0.40, repulsion=False)),
+    ]
+    for name, d in cases:
+        c = getattr(m, name)(["A"])
+        c.setParams("A", "A", d)
+        back = c.getParams("A", "A")
+        assert back.keys() == d.keys()
+        for k in d:
+            assert back[k] == pytest.approx(d[k], rel=1e-15) and type(back[k]) is type(d[k])
+    # only the modes the reference accepts (src/pair.py:215: DPD "none"; aniso pairs: none / shift)
+    with pytest.raises(RuntimeError):
+        m.PotentialPairDPDThermoGeneralWeightGPU(["A"]).mode = "shift"
+    a = m.AnisoPotentialPairTwoPatchMorseGPU(["A"])
+    a.mode = "shift"
+    with pytest.raises(RuntimeError):
+        a.mode = "xplor"
+    q = m.PotentialBondQuarticGPU(["A-A", "B-B"])
+    dq = dict(k=1434.3, r_0=1.5, b_1=-0.7589, b_2=0.0, U_0=67.2234, sigma=1.0, epsilon=1.0)
+    q.setParams("B-B", dq)  # delta defaults to 0 (src/bond.py:153)
+    assert q.getParams("B-B") == dict(dq, delta=0.0)
+    assert np.array_equal(np.frombuffer(q.params_bytes(), dtype=np.float64).reshape(2, 8)[1], oracle.pack_bond_params("Quartic", dict(dq, delta=0.0)))
+    w = m.PotentialBondDoubleWellGPU(["A-A"])
+    dw = dict(r_0=1.0, r_1=2.0, U_1=1.0, U_tilt=0.5)
+    w.setParams("A-A", dw)
+    assert w.getParams("A-A") == dw
