@@ -120,6 +120,18 @@ class NVEArgs(C.Structure):
     ]
 
 
+class NVERotArgs(C.Structure):
+    _fields_ = [
+        ("d_orientation", C.c_void_p),
+        ("d_angmom", C.c_void_p),
+        ("d_inertia", C.c_void_p),
+        ("d_net_torque", C.c_void_p),
+        ("dt", C.c_double),
+        ("N", C.c_uint32),
+        ("block_size", C.c_uint32),
+    ]
+
+
 class PlanInfo(C.Structure):
     _fields_ = [
         ("valid", C.c_int32),
@@ -220,6 +232,7 @@ SYMBOLS = {
     "azp_nlist_cell_bounds": (C.c_int, [C.POINTER(NlistArgs), _VP]),
     "azp_nlist_count": (C.c_int, [C.POINTER(NlistArgs), _VP]),
     "azp_nlist_fill": (C.c_int, [C.POINTER(NlistArgs), _VP]),
+    "azp_sorter_keys": (C.c_int, [C.c_uint32, _VP, C.POINTER(Box), C.POINTER(C.c_uint32), C.c_uint32, _VP, _VP]),
     "azp_halo_pack": (C.c_int, [C.c_uint32, _VP, _VP, C.c_uint32, _VP, _VP]),
     "azp_halo_pack_fields": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(HaloField), _VP, _VP, C.c_uint32, _VP]),
     "azp_halo_unpack_fields": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(HaloField), _VP, C.c_uint32, _VP]),
@@ -230,6 +243,8 @@ SYMBOLS = {
     "azp_spherical_barrier_valid": (C.c_int, [_D, C.POINTER(Box)]),
     "azp_integrate_nve_step_one": (C.c_int, [C.POINTER(NVEArgs), _VP]),
     "azp_integrate_nve_step_two": (C.c_int, [C.POINTER(NVEArgs), _VP]),
+    "azp_integrate_nve_rot_step_one": (C.c_int, [C.POINTER(NVERotArgs), _VP]),
+    "azp_integrate_nve_rot_step_two": (C.c_int, [C.POINTER(NVERotArgs), _VP]),
     "azp_version": (C.c_int, []),
     "azp_status_string": (C.c_char_p, [C.c_int]),
     "azp_last_launch": (None, [C.POINTER(C.c_uint32)] * 4),

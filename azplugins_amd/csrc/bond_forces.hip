@@ -49,11 +49,8 @@ __global__ void __launch_bounds__(256) bond_forces_kernel(const BondKArgs a, con
     const double4 p = load_scalar4(a.pos, idx);
     double fx = 0.0, fy = 0.0, fz = 0.0, pe = 0.0;
     double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (uint32_t b = 0; b < nb; ++b)
+    auto one_bond = [&](const azp_bond_entry& ent, uint32_t my_pos, const double3& q)
         {
-        const azp_bond_entry ent = a.bondlist[(uint64_t)b * a.pitch + idx];
-        const uint32_t my_pos = a.bond_pos[(uint64_t)b * a.pitch + idx];
-        const double3 q = load_scalar3_of4(a.pos, ent.idx);
         // dx = x_a - x_b with a the first member of the bond
         double dx, dy, dz;
         if (my_pos == 0) { dx = p.x - q.x; dy = p.y - q.y; dz = p.z - q.z; }
@@ -78,6 +75,37 @@ __global__ void __launch_bounds__(256) bond_forces_kernel(const BondKArgs a, con
             }
         else
             *d_flags = 1u;
+        };
+    // The first BATCH table columns of every lane are loaded together, then the partner
+    // positions together: two dependent round trips per particle instead of two per bond
+    // (a linear chain has <= 2 bonds per bead). The table reads are coalesced (column-major);
+    // the partner position is the only gather.
+    constexpr uint32_t BATCH = 4;
+    azp_bond_entry ent[BATCH];
+    uint32_t my_pos[BATCH];
+#pragma unroll
+    for (uint32_t b = 0; b < BATCH; ++b)
+        {
+        ent[b].idx = idx; ent[b].type = 0; my_pos[b] = 0;
+        if (b < nb)
+            {
+            ent[b] = a.bondlist[(uint64_t)b * a.pitch + idx];
+            my_pos[b] = a.bond_pos[(uint64_t)b * a.pitch + idx];
+            }
+        }
+    double3 q[BATCH];
+#pragma unroll
+    for (uint32_t b = 0; b < BATCH; ++b)
+        q[b] = load_scalar3_of4(a.pos, ent[b].idx); // unused slots re-read the lane's own (cached) row
+#pragma unroll
+    for (uint32_t b = 0; b < BATCH; ++b)
+        if (b < nb)
+            one_bond(ent[b], my_pos[b], q[b]);
+    for (uint32_t b = BATCH; b < nb; ++b)
+        {
+        const azp_bond_entry e = a.bondlist[(uint64_t)b * a.pitch + idx];
+        const uint32_t mp = a.bond_pos[(uint64_t)b * a.pitch + idx];
+        one_bond(e, mp, load_scalar3_of4(a.pos, e.idx));
         }
     store_scalar4(a.force, idx, fx, fy, fz, pe);
     if (a.compute_virial)

@@ -346,3 +346,132 @@ extern "C" int azp_halo_unpack_fields(uint32_t n, uint32_t n_fields, const azp_h
     {
     return azp::launch_halo_fields<false>(n, n_fields, fields, nullptr, const_cast<void*>(d_packed), packed_row_bytes, stream);
     }
+
+// ---- rotational half of the NVE step (azp_nve_rot_args, include/azp.h) ----
+namespace azp
+{
+struct Quat
+    {
+    double s, x, y, z;
+    };
+__device__ __forceinline__ void free_rotation(int axis, Quat& p, Quat& q, double I, double dt)
+    {
+    Quat pk, qk;
+    if (axis == 3)
+        {
+        pk = Quat {-p.z, p.y, -p.x, p.s};
+        qk = Quat {-q.z, q.y, -q.x, q.s};
+        }
+    else if (axis == 2)
+        {
+        pk = Quat {-p.y, -p.z, p.s, p.x};
+        qk = Quat {-q.y, -q.z, q.s, q.x};
+        }
+    else
+        {
+        pk = Quat {-p.x, p.s, p.z, -p.y};
+        qk = Quat {-q.x, q.s, q.z, -q.y};
+        }
+    const double phi = 0.25 / I * (p.s * qk.s + p.x * qk.x + p.y * qk.y + p.z * qk.z);
+    const double c = cos(dt * phi), sn = sin(dt * phi);
+    p = Quat {c * p.s + sn * pk.s, c * p.x + sn * pk.x, c * p.y + sn * pk.y, c * p.z + sn * pk.z};
+    q = Quat {c * q.s + sn * qk.s, c * q.x + sn * qk.x, c * q.y + sn * qk.y, c * q.z + sn * qk.z};
+    }
+
+template<bool STEP_ONE> __global__ void __launch_bounds__(256) nve_rot_kernel(const azp_nve_rot_args a)
+    {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.N)
+        return;
+    const double4 q4 = load_scalar4(a.d_orientation, i), p4 = load_scalar4(a.d_angmom, i), t4 = load_scalar4(a.d_net_torque, i);
+    Quat q = {q4.x, q4.y, q4.z, q4.w}, p = {p4.x, p4.y, p4.z, p4.w};
+    const double Ix = a.d_inertia[3ull * i], Iy = a.d_inertia[3ull * i + 1], Iz = a.d_inertia[3ull * i + 2];
+    // torque into the body frame: rotate(conj(q), t)
+    const double ux = -q.x, uy = -q.y, uz = -q.z;
+    const double c = q.s * q.s - (ux * ux + uy * uy + uz * uz);
+    const double d = 2.0 * (ux * t4.x + uy * t4.y + uz * t4.z);
+    double tx = c * t4.x + 2.0 * q.s * (uy * t4.z - uz * t4.y) + d * ux;
+    double ty = c * t4.y + 2.0 * q.s * (uz * t4.x - ux * t4.z) + d * uy;
+    double tz = c * t4.z + 2.0 * q.s * (ux * t4.y - uy * t4.x) + d * uz;
+    if (Ix == 0.0) tx = 0.0;
+    if (Iy == 0.0) ty = 0.0;
+    if (Iz == 0.0) tz = 0.0;
+    // p += dt * q * (0, t)
+    p.s += a.dt * -(q.x * tx + q.y * ty + q.z * tz);
+    p.x += a.dt * (q.s * tx + (q.y * tz - q.z * ty));
+    p.y += a.dt * (q.s * ty + (q.z * tx - q.x * tz));
+    p.z += a.dt * (q.s * tz + (q.x * ty - q.y * tx));
+    if (STEP_ONE)
+        {
+        if (Iz != 0.0) free_rotation(3, p, q, Iz, 0.5 * a.dt);
+        if (Iy != 0.0) free_rotation(2, p, q, Iy, 0.5 * a.dt);
+        if (Ix != 0.0) free_rotation(1, p, q, Ix, a.dt);
+        if (Iy != 0.0) free_rotation(2, p, q, Iy, 0.5 * a.dt);
+        if (Iz != 0.0) free_rotation(3, p, q, Iz, 0.5 * a.dt);
+        const double n = 1.0 / sqrt(q.s * q.s + q.x * q.x + q.y * q.y + q.z * q.z);
+        store_scalar4(a.d_orientation, i, q.s * n, q.x * n, q.y * n, q.z * n);
+        }
+    store_scalar4(a.d_angmom, i, p.s, p.x, p.y, p.z);
+    }
+
+template<bool STEP_ONE> static int launch_nve_rot(const azp_nve_rot_args* args, void* stream)
+    {
+    if (!args)
+        return AZP_ERROR_INVALID_ARGUMENT;
+    if (args->N == 0)
+        return AZP_SUCCESS;
+    if (!args->d_orientation || !args->d_angmom || !args->d_inertia || !args->d_net_torque)
+        return AZP_ERROR_INVALID_ARGUMENT;
+    const uint32_t bs = args->block_size ? args->block_size : 256u;
+    if (bs % 64 || bs > 256)
+        return AZP_ERROR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(nve_rot_kernel<STEP_ONE>, dim3((args->N + bs - 1) / bs), dim3(bs), 0, static_cast<hipStream_t>(stream), *args);
+    return (int)hipGetLastError();
+    }
+} // namespace azp
+
+extern "C" int azp_integrate_nve_rot_step_one(const azp_nve_rot_args* args, void* stream)
+    {
+    return azp::launch_nve_rot<true>(args, stream);
+    }
+extern "C" int azp_integrate_nve_rot_step_two(const azp_nve_rot_args* args, void* stream)
+    {
+    return azp::launch_nve_rot<false>(args, stream);
+    }
+
+// ---- particle sorter: blocked cell-curve keys in one launch ----
+namespace azp
+{
+__global__ void __launch_bounds__(256) sorter_keys_kernel(uint32_t n, const double* __restrict__ pos, BoxDev box, double cell_width, uint32_t dimx,
+                                                          uint32_t dimy, uint32_t dimz, uint32_t block, int32_t* __restrict__ keys)
+    {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n)
+        return;
+    const double3 p = load_scalar3_of4(pos, i);
+    // fractional coordinate in [0, 1): particles slightly outside the box wrap around
+    double fx = p.x * box.Lxinv + 0.5, fy = p.y * box.Lyinv + 0.5, fz = p.z * box.Lzinv + 0.5;
+    fx -= floor(fx); fy -= floor(fy); fz -= floor(fz);
+    const uint32_t cx = min((uint32_t)(fx * dimx), dimx - 1), cy = min((uint32_t)(fy * dimy), dimy - 1), cz = min((uint32_t)(fz * dimz), dimz - 1);
+    const uint32_t nbx = (dimx + block - 1) / block, nby = (dimy + block - 1) / block;
+    const uint32_t key = ((cz / block) * nby + (cy / block)) * nbx + (cx / block);
+    const uint32_t inner = ((cz % block) * block + (cy % block)) * block + (cx % block);
+    keys[i] = (int32_t)(key * (block * block * block) + inner);
+    }
+} // namespace azp
+
+extern "C" int azp_sorter_keys(uint32_t n, const double* d_pos, const azp_box* box, const uint32_t* dims, uint32_t block, int32_t* d_keys,
+                               void* stream)
+    {
+    if (n == 0)
+        return AZP_SUCCESS;
+    if (!d_pos || !box || !dims || !d_keys || block == 0 || dims[0] == 0 || dims[1] == 0 || dims[2] == 0)
+        return AZP_ERROR_INVALID_ARGUMENT;
+    const uint64_t nkeys = (uint64_t)((dims[0] + block - 1) / block) * ((dims[1] + block - 1) / block) * ((dims[2] + block - 1) / block)
+                           * block * block * block;
+    if (nkeys >= (1ull << 31))
+        return AZP_ERROR_INVALID_ARGUMENT; // keys are int32 (torch's fast sort path)
+    hipLaunchKernelGGL(azp::sorter_keys_kernel, dim3((n + 255u) / 256u), dim3(256), 0, static_cast<hipStream_t>(stream), n, d_pos,
+                       azp::make_box_dev(*box), 0.0, dims[0], dims[1], dims[2], block, d_keys);
+    return (int)hipGetLastError();
+    }

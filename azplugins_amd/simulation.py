@@ -37,12 +37,15 @@ class ConstantVolume:
 
 
 class Integrator:
-    """``hoomd.md.Integrator`` reduced: ``dt``, ``forces``, ``methods``."""
+    """``hoomd.md.Integrator`` reduced: ``dt``, ``forces``, ``methods``,
+    ``integrate_rotational_dof`` (orientations and angular momenta of particles with a
+    non-zero moment of inertia are integrated with the net torque, HOOMD's default False)."""
 
-    def __init__(self, dt, forces=None, methods=None):
+    def __init__(self, dt, forces=None, methods=None, integrate_rotational_dof=False):
         self.dt = float(dt)
         self.forces = list(forces) if forces is not None else []
         self.methods = list(methods) if methods is not None else []
+        self.integrate_rotational_dof = bool(integrate_rotational_dof)
 
 
 class _Operations:
@@ -162,6 +165,22 @@ class Simulation:
         lib = _lib.lib()
         stream = torch.cuda.current_stream(st.device).cuda_stream
 
+        rot = None
+        if integ.integrate_rotational_dof:
+            if self.domain is not None:
+                raise _lib.AzpError("integrate_rotational_dof is not supported in domain-decomposed runs yet")
+            rot = _lib.NVERotArgs()
+            rot.dt = integ.dt
+
+        def net_torque():
+            forces = integ.forces
+            if len(forces) == 1:
+                return forces[0].torque_tensor
+            t = forces[0].torque_tensor.clone()
+            for f in forces[1:]:
+                t += f.torque_tensor
+            return t
+
         def point_at_state():
             # (the arrays are replaced when particles migrate between ranks or are re-sorted)
             a.d_pos = st.pos.data_ptr()
@@ -170,10 +189,23 @@ class Simulation:
             a.d_image = st.image.data_ptr()
             a.N = st.N
 
+        def rotational_step(one):
+            torque = net_torque()  # kept alive until the kernel is queued
+            rot.d_orientation = st.orientation.data_ptr()
+            rot.d_angmom = st.angmom.data_ptr()
+            rot.d_inertia = st.inertia.data_ptr()
+            rot.d_net_torque = torque.data_ptr()
+            rot.N = st.N
+            fn = lib.azp_integrate_nve_rot_step_one if one else lib.azp_integrate_nve_rot_step_two
+            _lib.check(fn(C.byref(rot), stream), "azp_integrate_nve_rot_step")
+            return torque
+
         for _ in range(steps):
             # velocity Verlet (libazp kernels): v += a dt/2, x += v dt, wrap | forces | v += a dt/2
             point_at_state()
             _lib.check(lib.azp_integrate_nve_step_one(C.byref(a), stream), "azp_integrate_nve_step_one")
+            if rot is not None:
+                rotational_step(True)
             if self.domain is not None:
                 self.domain.exchange(self._halo_fields())  # ghost rows follow their owners' particles
             st.position_generation += 1
@@ -187,6 +219,8 @@ class Simulation:
             self._compute_forces()
             point_at_state()
             _lib.check(lib.azp_integrate_nve_step_two(C.byref(a), stream), "azp_integrate_nve_step_two")
+            if rot is not None:
+                rotational_step(False)
 
     def kinetic_temperature(self):
         """Instantaneous kT = 2 KE / (3 N - 3) (HOOMD ThermodynamicQuantities)."""
@@ -194,6 +228,19 @@ class Simulation:
         v = st.vel[: st.N]
         ke = 0.5 * float((v[:, 3] * (v[:, :3] ** 2).sum(dim=1)).sum().item())
         return 2.0 * ke / (3 * st.N - 3)
+
+    def rotational_kinetic_energy(self):
+        """sum_k s_k^2 / (2 I_k) over the axes with I_k != 0, s = 1/2 conj(q) p the body-frame
+        angular momentum (HOOMD ComputeThermo)."""
+        import torch
+
+        st = self.state
+        q, p, I = st.orientation[: st.N], st.angmom[: st.N], st.inertia[: st.N]
+        qs, qv = q[:, 0:1], q[:, 1:4]
+        ps, pv = p[:, 0:1], p[:, 1:4]
+        s_v = 0.5 * (qs * pv - ps * qv - torch.linalg.cross(qv, pv))  # vector part of conj(q) p / 2
+        ke = torch.where(I != 0.0, s_v * s_v / torch.where(I != 0.0, I, torch.ones_like(I)), torch.zeros_like(I))
+        return 0.5 * float(ke.sum().item())
 
     def thermalize_particle_momenta(self, kT, seed=12345):
         """Maxwell-Boltzmann velocities with zero total momentum."""

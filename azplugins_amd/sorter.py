@@ -20,23 +20,23 @@ class ParticleSorter:
         self.num_sorts = 0
 
     def keys(self, state):
-        """64-bit sort key per local particle: (block index, position inside the block)."""
+        """int32 sort key per local particle: (block index, position inside the block), one
+        libazp kernel (a chain of a dozen torch element-wise ops paid 170-550 ms of lazy kernel
+        loading on the first sort of a run)."""
+        import ctypes as C
+
         import torch
 
         N = state.N
-        L = torch.tensor(state.box.L, dtype=torch.float64, device=state.device)
         volume = float(np.prod(state.box.L))
         # cell width such that block^3 cells hold about particles_per_block particles
         w = (self.particles_per_block * volume / max(N, 1)) ** (1.0 / 3.0) / self.block
-        dims = torch.clamp(torch.floor(L / w), min=1).to(torch.int64)
-        frac = (state.pos[:N, :3] / L + 0.5)
-        frac = frac - torch.floor(frac)  # particles slightly outside the box wrap around
-        c = torch.minimum((frac * dims).to(torch.int64), dims - 1)
-        b = self.block
-        nb = (dims + b - 1) // b
-        key = ((c[:, 2] // b) * nb[1] + (c[:, 1] // b)) * nb[0] + (c[:, 0] // b)
-        inner = ((c[:, 2] % b) * b + (c[:, 1] % b)) * b + (c[:, 0] % b)
-        return (key * (b * b * b) + inner).to(torch.int32)  # < 2^31; int32 keys take torch's fast sort path
+        dims = (C.c_uint32 * 3)(*[max(int(np.floor(L / w)), 1) for L in state.box.L])
+        keys = torch.empty(N, dtype=torch.int32, device=state.device)
+        box = state.box.to_c()
+        stream = torch.cuda.current_stream(state.device).cuda_stream
+        _lib.check(_lib.lib().azp_sorter_keys(N, state.pos.data_ptr(), C.byref(box), dims, self.block, keys.data_ptr(), stream), "azp_sorter_keys")
+        return keys
 
     def sort(self, sim):
         """Reorder the state of ``sim`` in place; returns the permutation applied
@@ -51,7 +51,7 @@ class ParticleSorter:
             raise _lib.AzpError("ParticleSorter: decomposed states keep their interior | boundary | ghost order")
         N = st.N
         order = torch.sort(self.keys(st), stable=True).indices
-        for name in ("pos", "vel", "orientation", "tag", "image"):
+        for name in ("pos", "vel", "orientation", "tag", "image", "angmom", "inertia"):
             a = getattr(st, name)
             a[:N] = a[:N].index_select(0, order)
         if st.bond_group.shape[0]:

@@ -7,6 +7,7 @@ objects the reference's force classes are attached to (``hoomd.Snapshot``,
 * ``vel``   (n_max, 4) float64: vx, vy, vz, mass
 * ``orientation`` (n_max, 4) float64 quaternion, scalar part first
 * ``tag``   (n_max,) uint32 (stored as int32 bit pattern)
+* ``angmom`` (n_max, 4) float64 angular-momentum quaternion, ``inertia`` (n_max, 3) principal moments
 """
 
 import numpy as np
@@ -66,6 +67,7 @@ class _Particles:
         self.velocity = np.zeros((n, 3))
         self.mass = np.ones(n)
         self.moment_inertia = np.zeros((n, 3))
+        self.angmom = np.zeros((n, 4))
         self.tag = np.arange(n, dtype=np.uint32)
 
     @property
@@ -114,7 +116,7 @@ class Snapshot:
 
     @classmethod
     def from_arrays(cls, xyz, box, typeid=None, types=("A",), orientation=None, velocity=None, tag=None, bonds=None,
-                    bond_typeid=None, bond_types=("A-A",)):
+                    bond_typeid=None, bond_types=("A-A",), moment_inertia=None, angmom=None):
         s = cls()
         xyz = np.asarray(xyz, dtype=np.float64)
         s.particles.N = xyz.shape[0]
@@ -128,6 +130,10 @@ class Snapshot:
             s.particles.velocity[:] = velocity
         if tag is not None:
             s.particles.tag[:] = tag
+        if moment_inertia is not None:
+            s.particles.moment_inertia[:] = moment_inertia
+        if angmom is not None:
+            s.particles.angmom[:] = angmom
         s.configuration.box = Box.from_box(box)
         if bonds is not None:
             bonds = np.asarray(bonds, dtype=np.uint32).reshape(-1, 2)
@@ -198,6 +204,9 @@ class State:
         self.vel = torch.from_numpy(vel).to(self.device)
         self.orientation = torch.from_numpy(np.ascontiguousarray(p.orientation, dtype=np.float64)).to(self.device)
         self.tag = torch.from_numpy(np.ascontiguousarray(p.tag, dtype=np.uint32).view(np.int32)).to(self.device)
+        # rotational degrees of freedom (HOOMD ParticleData: angmom Scalar4, moment_inertia Scalar3)
+        self.angmom = torch.from_numpy(np.ascontiguousarray(p.angmom, dtype=np.float64)).to(self.device)
+        self.inertia = torch.from_numpy(np.ascontiguousarray(p.moment_inertia, dtype=np.float64)).to(self.device)
         self.net_force = torch.zeros((self.N, 4), dtype=f64, device=self.device)
         self.image = torch.zeros((p.N, 3), dtype=torch.int32, device=self.device)
         b = snapshot.bonds

@@ -385,6 +385,12 @@ int azp_nlist_fill(const azp_nlist_args* args, void* stream);
 int azp_nlist_distance_check(uint32_t n, const double* d_pos, const double* d_pos_at_build, const azp_box* box,
                              double max_dist_sq, uint32_t* d_flag, unsigned long long* d_max_dist_sq_bits, void* stream);
 
+/* Sort keys of the particle sorter (the role of HOOMD's SFC sorter, which the tile plan relies
+ * on): key of particle i = index of its cell along a blocked curve over a dims[0] x dims[1] x
+ * dims[2] grid (block^3 cells per block), positions wrapped into the orthorhombic frame of `box`. */
+int azp_sorter_keys(uint32_t n, const double* d_pos, const azp_box* box, const uint32_t* dims, uint32_t block, int32_t* d_keys,
+                    void* stream);
+
 /* ---- halo pack: dst[k, :] = src[idx[k], :] for k < n, rows of
  * row_doubles doubles (4 for positions / velocities / orientations). The send buffer of
  * the per-step ghost exchange; replaces the pack half of HOOMD's CommunicatorGPU. */
@@ -457,6 +463,29 @@ typedef struct azp_nve_args
 
 int azp_integrate_nve_step_one(const azp_nve_args* args, void* stream);
 int azp_integrate_nve_step_two(const azp_nve_args* args, void* stream);
+
+/* Rotational degrees of freedom of the same step ("+ rotational for
+ * aniso"; the reference's aniso test gives its particles a moment of inertia,
+ * src/pytest/test_pair_aniso.py:113-140): HOOMD's integrate_rotational_dof path restated -- the
+ * symplectic NO_SQUISH quaternion scheme. q = d_orientation (scalar first), p = d_angmom (angular
+ * momentum quaternion; body angular momentum = 1/2 conj(q) p), per-particle principal moments
+ * d_inertia (N x 3; an axis with zero moment is not integrated), d_net_torque (N x 4, space
+ * frame). step one: p += dt q t_body, free rotations about axes 3, 2, 1, 2, 3, q renormalised;
+ * step two: p += dt q t_body. HOOMD-blue's source is absent here: PARITY UNPINNED (pinned by
+ * conservation properties, tests/test_gpu_external_nve.py). */
+typedef struct azp_nve_rot_args
+    {
+    double* d_orientation;      /* N x 4 */
+    double* d_angmom;           /* N x 4 */
+    const double* d_inertia;    /* N x 3 */
+    const double* d_net_torque; /* N x 4 */
+    double dt;
+    uint32_t N;
+    uint32_t block_size;
+    } azp_nve_rot_args;
+
+int azp_integrate_nve_rot_step_one(const azp_nve_rot_args* args, void* stream);
+int azp_integrate_nve_rot_step_two(const azp_nve_rot_args* args, void* stream);
 
 /* ---- misc ---- */
 int azp_version(void);                    /* major * 1000 + minor       */

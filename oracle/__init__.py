@@ -440,3 +440,18 @@ def nve_step(step_one, pos, vel, net_force, box, dt):
     """In-place velocity-Verlet half step on (n,4) pos / vel arrays."""
     b = box if isinstance(box, Box) else make_box(*box)
     lib().azo_nve_step(int(bool(step_one)), pos.shape[0], _p(pos), _p(vel), _p(np.ascontiguousarray(net_force)), C.byref(b), float(dt))
+
+
+def nve_rot_step(step_one, orientation, angmom, inertia, net_torque, dt):
+    """Rotational half of the NVE step, in place on copies; returns (orientation, angmom).
+    PARITY UNPINNED against HOOMD (see azp_oracle.c: azo_nve_rot_step)."""
+    q = np.ascontiguousarray(orientation, dtype=np.float64).copy()
+    p = np.ascontiguousarray(angmom, dtype=np.float64).copy()
+    I = np.ascontiguousarray(inertia, dtype=np.float64)
+    t = np.ascontiguousarray(net_torque, dtype=np.float64)
+    l = lib()
+    l.azo_nve_rot_step.restype = None
+    l.azo_nve_rot_step.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+    l.azo_nve_rot_step(int(bool(step_one)), q.shape[0], q.ctypes.data, p.ctypes.data, I.ctypes.data, t.ctypes.data, float(dt))
+    return q, p
+

@@ -1298,6 +1298,90 @@ void azo_nve_step(int step_one, int64_t N, Scalar* pos, Scalar* vel, const Scala
         }
     }
 
+/* Rotational half of the velocity-Verlet NVE step (HOOMD TwoStepConstantVolume with
+ * integrate_rotational_dof, restated from recollection of hoomd/md/TwoStepConstantVolume.cc:
+ * the symplectic NO_SQUISH scheme of Miller et al. / Kamberaj et al.). HOOMD-blue's source is
+ * absent, so this restatement is PARITY UNPINNED; the reference only exercises it through
+ * `moment_inertia` in src/pytest/test_pair_aniso.py:113-140. Pinned here by: free rotation
+ * conserves |L| and the rotational kinetic energy, and total energy is conserved with the
+ * TwoPatchMorse torques (tests/test_gpu_external_nve.py).
+ *   q: orientation (scalar first), p: angular-momentum quaternion (body angular momentum
+ *   s = 1/2 conj(q) p), I: principal moments, t: net torque (space frame).
+ *   step one: p += dt q t_body; free rotations 3 (dt/2), 2 (dt/2), 1 (dt), 2 (dt/2), 3 (dt/2);
+ *             q renormalised.   step two: p += dt q t_body.
+ * An axis with zero moment of inertia is not integrated. */
+static void q_mul_vec(const Scalar* q, const Scalar* t, Scalar* out) /* (s, v) * (0, t) */
+    {
+    out[0] = -(q[1] * t[0] + q[2] * t[1] + q[3] * t[2]);
+    out[1] = q[0] * t[0] + (q[2] * t[2] - q[3] * t[1]);
+    out[2] = q[0] * t[1] + (q[3] * t[0] - q[1] * t[2]);
+    out[3] = q[0] * t[2] + (q[1] * t[1] - q[2] * t[0]);
+    }
+static void rotate_conj(const Scalar* q, const Scalar* v, Scalar* out) /* rotate(conj(q), v) */
+    {
+    const Scalar s = q[0], ux = -q[1], uy = -q[2], uz = -q[3];
+    const Scalar c = s * s - (ux * ux + uy * uy + uz * uz);
+    const Scalar d = 2.0 * (ux * v[0] + uy * v[1] + uz * v[2]);
+    out[0] = c * v[0] + 2.0 * s * (uy * v[2] - uz * v[1]) + d * ux;
+    out[1] = c * v[1] + 2.0 * s * (uz * v[0] - ux * v[2]) + d * uy;
+    out[2] = c * v[2] + 2.0 * s * (ux * v[1] - uy * v[0]) + d * uz;
+    }
+static void free_rotation(int axis, Scalar* p, Scalar* q, Scalar I, Scalar dt)
+    {
+    Scalar pk[4], qk[4];
+    if (axis == 3)
+        {
+        pk[0] = -p[3]; pk[1] = p[2]; pk[2] = -p[1]; pk[3] = p[0];
+        qk[0] = -q[3]; qk[1] = q[2]; qk[2] = -q[1]; qk[3] = q[0];
+        }
+    else if (axis == 2)
+        {
+        pk[0] = -p[2]; pk[1] = -p[3]; pk[2] = p[0]; pk[3] = p[1];
+        qk[0] = -q[2]; qk[1] = -q[3]; qk[2] = q[0]; qk[3] = q[1];
+        }
+    else
+        {
+        pk[0] = -p[1]; pk[1] = p[0]; pk[2] = p[3]; pk[3] = -p[2];
+        qk[0] = -q[1]; qk[1] = q[0]; qk[2] = q[3]; qk[3] = -q[2];
+        }
+    const Scalar phi = 0.25 / I * (p[0] * qk[0] + p[1] * qk[1] + p[2] * qk[2] + p[3] * qk[3]);
+    const Scalar c = cos(dt * phi), sn = sin(dt * phi);
+    for (int k = 0; k < 4; ++k)
+        {
+        p[k] = c * p[k] + sn * pk[k];
+        q[k] = c * q[k] + sn * qk[k];
+        }
+    }
+void azo_nve_rot_step(int step_one, int64_t N, Scalar* orientation, Scalar* angmom, const Scalar* inertia, const Scalar* net_torque,
+                      Scalar dt)
+    {
+    for (int64_t i = 0; i < N; ++i)
+        {
+        Scalar* q = orientation + 4 * i;
+        Scalar* p = angmom + 4 * i;
+        const Scalar* I = inertia + 3 * i;
+        Scalar t[3], qt[4];
+        rotate_conj(q, net_torque + 4 * i, t);
+        for (int k = 0; k < 3; ++k)
+            if (I[k] == 0.0)
+                t[k] = 0.0;
+        q_mul_vec(q, t, qt);
+        for (int k = 0; k < 4; ++k)
+            p[k] += dt * qt[k];
+        if (step_one)
+            {
+            if (I[2] != 0.0) free_rotation(3, p, q, I[2], 0.5 * dt);
+            if (I[1] != 0.0) free_rotation(2, p, q, I[1], 0.5 * dt);
+            if (I[0] != 0.0) free_rotation(1, p, q, I[0], dt);
+            if (I[1] != 0.0) free_rotation(2, p, q, I[1], 0.5 * dt);
+            if (I[2] != 0.0) free_rotation(3, p, q, I[2], 0.5 * dt);
+            const Scalar n = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+            for (int k = 0; k < 4; ++k)
+                q[k] *= n;
+            }
+        }
+    }
+
 size_t azo_sizeof(int what)
     {
     switch (what)

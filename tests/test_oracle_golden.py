@@ -181,3 +181,63 @@ def test_external_barrier_known_answers(oracle, kind):
         f = oracle.barrier_forces(kind, pos, box, params, r["location"])
         np.testing.assert_allclose(f[:, 3], r["energies"], atol=1e-4)
         np.testing.assert_allclose(f[:, :3], r["forces"], atol=1e-4)
+
+
+def test_rotational_nve_free_top_conserves_momentum_and_energy(oracle):
+    """azo_nve_rot_step (the rotational half of the NVE step, PARITY UNPINNED against HOOMD:
+    its source is absent) on torque-free asymmetric tops: the space-frame angular momentum
+    and the rotational kinetic energy are constants of the motion; the NO_SQUISH free
+    rotations conserve |L| to rounding and the energy to O(dt^2); q stays normalised; bodies
+    with a zero moment of inertia (no rotation about that axis, no energy term) are included."""
+    rng = np.random.default_rng(3)
+    n = 64
+    q = rng.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1)[:, None]
+    I = np.tile(np.array([0.4, 0.7, 1.1]), (n, 1))
+    I[:8, 2] = 0.0  # rods: no rotation about the body z axis
+    s_body = rng.normal(size=(n, 3))
+    s_body[:8, 2] = 0.0
+
+    def qmul(a, b):
+        s = a[:, :1] * b[:, :1] - (a[:, 1:] * b[:, 1:]).sum(1, keepdims=True)
+        v = a[:, :1] * b[:, 1:] + b[:, :1] * a[:, 1:] + np.cross(a[:, 1:], b[:, 1:])
+        return np.concatenate([s, v], axis=1)
+
+    def body(q, p):  # s = 1/2 conj(q) p
+        qc = q * np.array([1.0, -1.0, -1.0, -1.0])
+        return 0.5 * qmul(qc, p)[:, 1:]
+
+    def space(q, s):  # rotate(q, s)
+        qc = q * np.array([1.0, -1.0, -1.0, -1.0])
+        return qmul(qmul(q, np.concatenate([np.zeros((len(s), 1)), s], axis=1)), qc)[:, 1:]
+
+    def ke(q, p):
+        s = body(q, p)
+        return 0.5 * np.where(I != 0.0, s * s / np.where(I != 0.0, I, 1.0), 0.0).sum(axis=1)
+
+    p = 2.0 * qmul(q, np.concatenate([np.zeros((n, 1)), s_body], axis=1))
+    assert np.allclose(body(q, p), s_body)
+    zero = np.zeros((n, 4))
+    L0, E0 = space(q, body(q, p)), ke(q, p)
+    drift = []
+    for dt in (0.01, 0.005):
+        qq, pp = q.copy(), p.copy()
+        for _ in range(int(round(2.0 / dt))):
+            qq, pp = oracle.nve_rot_step(True, qq, pp, I, zero, dt)
+            qq, pp = oracle.nve_rot_step(False, qq, pp, I, zero, dt)
+        assert np.allclose(np.linalg.norm(qq, axis=1), 1.0, atol=1e-14)
+        assert np.allclose(np.linalg.norm(space(qq, body(qq, pp)), axis=1), np.linalg.norm(L0, axis=1), rtol=1e-10)
+        assert np.abs(space(qq, body(qq, pp)) - L0).max() < 2e-3 * (dt / 0.01) ** 2 * np.abs(L0).max() + 1e-12
+        drift.append(np.abs(ke(qq, pp) - E0).max() / E0.max())
+        assert not np.allclose(qq, q)  # it did rotate
+    assert drift[0] < 1e-3 and drift[1] < 0.3 * drift[0] + 1e-12  # second order in dt
+    # a constant body-frame torque about a principal axis of a top at rest: s_x grows as torque * t
+    q1 = np.tile(np.array([1.0, 0.0, 0.0, 0.0]), (n, 1))
+    p1 = np.zeros((n, 4))
+    tq = np.zeros((n, 4))
+    tq[:, 0] = 0.3
+    dt = 0.01
+    for _ in range(100):
+        q1, p1 = oracle.nve_rot_step(True, q1, p1, I, tq, dt)
+        q1, p1 = oracle.nve_rot_step(False, q1, p1, I, tq, dt)
+    assert np.allclose(body(q1, p1)[:, 0], 0.3 * 1.0, rtol=1e-10)
