@@ -71,7 +71,9 @@ template<class Args> azp_pair_args common_pair_args(const Args& args)
     a.shift_mode = args.shift_mode; // 0 none, 1 shift, 2 xplor: same encoding
     a.compute_virial = args.compute_virial;
     a.block_size = 0;               // library default
-    a.threads_per_particle = 0;     // library heuristic
+    a.threads_per_particle = 0;     // 0: libazp's own cached tile plan; HOOMD's autotuner
+                                    // value (args.threads_per_particle) would select the generic kernel
+    a.flags = 0;
     return a;
     }
     } // namespace
@@ -145,7 +147,7 @@ gpu_compute_pair_aniso_forces<azplugins::detail::AnisoPairEvaluatorTwoPatchMorse
         b.d_gpu_n_bonds = args.d_gpu_n_bonds;                                                                \
         b.pitch = args.gpu_table_indexer.getW();                                                             \
         b.n_bond_types = args.n_bond_types;                                                                  \
-        b.compute_virial = 1;                                                                                \
+        b.compute_virial = 1; /* bond_args_t has no such flag: HOOMD's bond kernels always write the virial */ \
         return to_hip(ENTRY(&b, reinterpret_cast<const PARAMS*>(d_params), d_flags, nullptr));               \
         }
 

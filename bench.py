@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--tpp", type=int, default=0, help="threads per particle (0 = library heuristic)")
     ap.add_argument("--block-size", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-figures", action="store_true",
+                    help="only the timed region (profiler passes: every launch of the kernel belongs to the cycle)")
     ap.add_argument("--mode", default="none", choices=["none", "shift", "xplor"])
     ap.add_argument("--no-plan", action="store_true", help="generic kernel only (no LDS-staged tile plan)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
@@ -277,19 +279,33 @@ def main():
         st.position_generation += 1
         nl.assume_displacement(st, bounds[k])  # known from the recorded run: no distance-check kernel in the timed loop
 
-    def step(k):
-        set_state(k % n_states)
+    # Timed order: the K steps walk through the cycle ONCE, steps // n_states consecutive launches on
+    # each state (state of step k = k * n_states // K), so that every cycle step carries the same
+    # weight and each launch reads positions that are as warm in the caches as they are in an MD
+    # run, where the integrator has just written them. (Switching to another 32 MB snapshot at
+    # every launch makes each launch stage positions that left the Infinity Cache eight launches
+    # earlier: +7-9 % per launch; that order is timed after the region as a side figure.)
+    def state_of(k, total):
+        return min(k * n_states // max(total, 1), n_states - 1)
+
+    def step(k, total, blocked=True):
+        s = state_of(k, total) if blocked else k % n_states
+        if step.current != s:
+            set_state(s)
+            step.current = s
         pot.compute(0)
 
+    step.current = -1
     for k in range(args.warmup):
-        step(k)
+        step(k, args.warmup)
+    step.current = -1
     torch.cuda.synchronize()
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
     for k in range(args.steps):
-        step(k)
+        step(k, args.steps)
     ev1.record()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
@@ -309,11 +325,23 @@ def main():
 
     by_step = []
     for k in range(n_states):
+        if args.no_side_figures:
+            break
         set_state(k)
         by_step.append(dict(step=k, displacement_bound=bounds[k], bound_over_half_buffer=bounds[k] / (0.5 * r_buff), kernel_ms=timed()))
-    set_state(0)
     side = {}
-    if pot.use_displacement_bound and not args.sort_rows and args.displace == 0.0:
+    if n_states > 1 and not args.no_side_figures:
+        # the same K launches, switching to the next cycle step at every launch (cold positions)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        step.current = -1
+        e0.record()
+        for k in range(args.steps):
+            step(k, args.steps, blocked=False)
+        e1.record()
+        torch.cuda.synchronize()
+        side["cycle_mean_ms_switching_state_every_launch"] = e0.elapsed_time(e1) / args.steps
+    set_state(0)
+    if pot.use_displacement_bound and not args.sort_rows and args.displace == 0.0 and not args.no_side_figures:
         side["static_list_bound_0_ms"] = timed()  # round 1's headline state
         pot.use_displacement_bound = False
         side["whole_rows_no_displacement_information_ms"] = timed()
@@ -349,9 +377,10 @@ def main():
     valu, valu_src = committed_counter(kernel_name, cfg["name"], "SQ_INSTS_VALU")
     cycle_desc = ("static list: the snapshot the list was built for, displacement bound 0" if n_states == 1 else
                   "one neighbor-list rebuild cycle of an NVE run (Maxwell velocities kT=%.2f on the workload's snapshot, dt=0.005; "
-                  "%d steps until HOOMD's distance check asks for a rebuild); timed step k uses the positions of cycle step "
-                  "k mod %d with the displacement bound that step's distance check returned; list and plan built once for "
-                  "step 0, not rebuilt" % (args.kT, n_states, n_states))
+                  "%d steps until HOOMD's distance check asks for a rebuild); the K timed steps walk through the cycle once, "
+                  "K / %d consecutive launches on the positions of each cycle step with the displacement bound that step's "
+                  "distance check returned; list and plan built once for step 0, not rebuilt"
+                  % (args.kT, n_states, n_states))
     out = {
         "metric": "particle-steps/sec, PerturbedLennardJones pair force",
         "value": value,
