@@ -74,6 +74,9 @@ class Simulation:
         any rank's distance check asks for a neighbor-list rebuild, all ranks migrate their
         particles and re-select their ghosts first (HOOMD: Communicator::migrateParticles /
         exchangeGhosts ahead of NeighborList::compute)."""
+        if self.state.bond_group.shape[0]:
+            raise _lib.AzpError("attach_domain: bonded systems are not supported in decomposed runs yet (the bond table "
+                                "holds local indices and does not migrate)")
         self.domain = domain
         domain.attach_state(self.state)
         self.operations.tuners.clear()  # the domain keeps its own interior | boundary | ghost order
