@@ -141,10 +141,14 @@ class PlanInfo(C.Structure):
         ("lds_slots", C.c_uint32),
         ("n_tiles", C.c_uint32),
         ("max_stage", C.c_uint32),
-        ("_pad", C.c_uint32),
+        ("max_row", C.c_uint32),
         ("total_stage", C.c_uint64),
         ("compiled_bytes", C.c_uint64),
         ("builds", C.c_uint64),
+        ("from_cells", C.c_int32),
+        ("row_capacity", C.c_uint32),
+        ("list_id", C.c_uint64),
+        ("head_id", C.c_uint64),
     ]
 
 
@@ -213,6 +217,7 @@ SYMBOLS = {
     "azp_pair_plan_create": (C.c_int, [C.POINTER(_VP)]),
     "azp_pair_plan_destroy": (None, [_VP]),
     "azp_pair_plan_build": (C.c_int, [_VP, C.POINTER(PairArgs), _VP]),
+    "azp_pair_plan_build_from_cells": (C.c_int, [_VP, C.POINTER(NlistArgs), C.POINTER(PairArgs), _VP]),
     "azp_pair_plan_set_bank_order": (C.c_int, [_VP, C.c_int]),
     "azp_pair_plan_query": (C.c_int, [_VP, C.POINTER(PlanInfo)]),
     "azp_pair_auto_plan_get_stats": (None, [C.POINTER(AutoPlanStats)]),
@@ -322,6 +327,9 @@ class PairPlan:
 
     def build(self, args, stream):
         check(lib().azp_pair_plan_build(self._h, C.byref(args), stream), "azp_pair_plan_build")
+
+    def build_from_cells(self, cells, pair, stream):
+        check(lib().azp_pair_plan_build_from_cells(self._h, C.byref(cells), C.byref(pair), stream), "azp_pair_plan_build_from_cells")
 
     def set_bank_order(self, enabled):
         check(lib().azp_pair_plan_set_bank_order(self._h, int(bool(enabled))), "azp_pair_plan_set_bank_order")

@@ -375,7 +375,7 @@ extern "C" int azp_aniso_forces_planned_two_patch_morse(azp_pair_plan* plan_, co
     if (plan.builds == 0 || plan.N != args->pair.N || plan.nlist_ptr != args->pair.d_nlist || plan.head_ptr != args->pair.d_head_list)
         return AZP_ERROR_INVALID_ARGUMENT; // a plan compiled from a different list is a caller bug
     if (!xtiled_usable(plan, args->pair))
-        return azp_aniso_forces_two_patch_morse(args, d_params, stream);
+        return plan.from_cells ? AZP_ERROR_INVALID_ARGUMENT : azp_aniso_forces_two_patch_morse(args, d_params, stream);
     XTPM::KExtra x;
     x.orientation = args->d_orientation;
     x.torque = args->d_torque;

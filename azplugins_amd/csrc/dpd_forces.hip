@@ -323,7 +323,7 @@ extern "C" int azp_dpd_forces_planned_general_weight(azp_pair_plan* plan_, const
     if (plan.builds == 0 || plan.N != args->pair.N || plan.nlist_ptr != args->pair.d_nlist || plan.head_ptr != args->pair.d_head_list)
         return AZP_ERROR_INVALID_ARGUMENT; // a plan compiled from a different list is a caller bug
     if (!xtiled_usable(plan, args->pair))
-        return azp_dpd_forces_general_weight(args, d_params, stream);
+        return plan.from_cells ? AZP_ERROR_INVALID_ARGUMENT : azp_dpd_forces_general_weight(args, d_params, stream);
     XDPD::KExtra x;
     x.vel = args->d_vel; x.tag = args->d_tag; x.timestep = args->timestep; x.deltaT = args->deltaT; x.T = args->T;
     x.seed = args->seed; x._pad = 0;

@@ -44,7 +44,7 @@ struct EvalPLJ
         const double lam = p.attraction_scale_factor;
         const double wca_shift = p.epsilon_x_4 * (1.0 - lam) / 4.0;
         double e_cut = 0.0;
-        if (energy_shift)
+        if (energy_shift && rcutsq > 0.0) // r_cut = 0: the pair never interacts; keep the blended offsets finite
             {
             const double rcut2inv = 1.0 / rcutsq;
             const double rcut6inv = rcut2inv * rcut2inv * rcut2inv;

@@ -565,6 +565,7 @@ void plan_free(PairPlan& p)
     if (p.d_slice_head) (void)hipFree(p.d_slice_head);
     if (p.d_cnl) (void)hipFree(p.d_cnl);
     if (p.d_flags) (void)hipFree(p.d_flags);
+    if (p.d_raw) (void)hipFree(p.d_raw);
     p = PairPlan();
     }
 
@@ -733,6 +734,7 @@ int plan_build(PairPlan& p, const azp_pair_args& args, hipStream_t s)
     {
     p.valid = false;
     p.invalid_reason = 0;
+    p.from_cells = false;
     p.N = args.N;
     p.n_max = args.n_max;
     p.nlist_ptr = args.d_nlist;
@@ -811,5 +813,10 @@ extern "C" int azp_pair_plan_query(const azp_pair_plan* plan, azp_pair_plan_info
     info->total_stage = p->total_stage;
     info->compiled_bytes = p->total_chunks * 64ull * 16ull;
     info->builds = p->builds;
+    info->max_row = p->max_row;
+    info->from_cells = p->from_cells ? 1 : 0;
+    info->row_capacity = p->row_cap;
+    info->list_id = reinterpret_cast<uint64_t>(p->nlist_ptr);
+    info->head_id = reinterpret_cast<uint64_t>(p->head_ptr);
     return AZP_SUCCESS;
     }

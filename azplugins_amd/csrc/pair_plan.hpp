@@ -76,6 +76,12 @@ struct PairPlan
     uint32_t* d_flags = nullptr;           // [1] stage overflow, [2] max staged set, [3] shell width, [4] max listed r^2 (float bits)
     size_t cap_tiles = 0, cap_slices = 0, cap_stage = 0, cap_cnl = 0, cap_kend = 0;
     uint64_t builds = 0;
+    // plans compiled straight from the cell list (pair_plan_cells.hip)
+    bool from_cells = false;
+    uint32_t row_cap = 0;           // entries a compiled row can hold (fixed chunk capacity per slice)
+    uint32_t max_row = 0;           // longest row seen (> row_cap: the caller retries with longer rows)
+    uint16_t* d_raw = nullptr;      // raw rows (candidate number | class), scratch of the build
+    size_t cap_raw = 0;
     bool bank_order = true;         // build option (azp_pair_plan_set_bank_order)
     uint32_t stage_stride_hint = 0; // stage_idx entries to reserve per tile next time (last max + 25 %)
     // host copy of d_tile_nstage: a launch over a sub-range of tiles (domain-decomposed
@@ -99,6 +105,7 @@ inline uint32_t plan_shells_for(const PairPlan& plan, const azp_pair_args& args)
     }
 
 int plan_build(PairPlan& p, const azp_pair_args& args, hipStream_t s); // pair_plan.hip
+int plan_build_from_cells(PairPlan& p, const azp_nlist_args& cells, const azp_pair_args& pair, hipStream_t s); // pair_plan_cells.hip
 void plan_free(PairPlan& p);
 
 inline uint32_t plan_cap_for(uint32_t max_stage)

@@ -1,0 +1,782 @@
+// pair_plan_cells.hip -- the tile plan compiled STRAIGHT FROM THE CELL LIST, in the pass
+// that finds the neighbors (SURVEY 8f row N1 + the plan of pair_plan.hpp in one kernel).
+//
+// pair_plan.hip compiles a plan from a finished HOOMD-format neighbor list: it has to
+// rediscover, per tile, which particles the rows mention (LDS hash set + sort) and walks
+// the u32 rows twice. An MD run that owns its neighbor search does not need the u32 list at
+// all. One workgroup of 256 threads per tile of 256 consecutive particles, THREAD = MEMBER
+// from the first phase to the last:
+//
+//   0. every member puts the 27 cells around its own into an LDS set (first member of a cell
+//      only); the set, sorted by cell number, is the tile's candidate space: cells that are
+//      consecutive along x are consecutive candidate ranges;
+//   1. per distinct member cell, the <= 18 runs of candidates (3 x 3 rows of cells along x,
+//      a row that wraps through the periodic boundary is two runs);
+//   2. the candidates are staged in LDS in batches of 1,024 (single-precision positions
+//      relative to the tile's reference particle); every thread walks the runs of its member
+//      through the batch, one candidate per step. An accepted candidate is appended to the
+//      member's raw row (candidate number | class, 2 B, global scratch laid out [entry][member]
+//      so that the 64 lanes of a wave write and later read one cache line), counted under its
+//      class (per-thread counters in LDS) and marked in a bitmap;
+//   3. the bitmap, compacted (prefix of popcounts), gives every used candidate its LDS slot
+//      of the force kernel; the stage list is written;
+//   4. every thread turns its raw row into the force kernel's compiled row: entries ordered
+//      class by class (a running cursor per class, seeded with the class totals of phase 2),
+//      slot byte offsets, 16-byte chunks in the kernel's lane order, chunk counts per class
+//      boundary for the displacement bound.
+//
+// No hash set of particles, no sort, no u32 rows, no host scan (slices have a fixed chunk
+// capacity), no cross-lane compaction anywhere (each lane owns its row), one synchronisation
+// (flags). The accepted set is a SUPERSET of the exact list by a hair (single-precision test
+// with a 1e-5 margin on r_list^2): extra entries are buffer entries the force kernel's exact
+// FP64 cutoff test ignores. Classes are conservative exactly as in pair_plan.hip.
+//
+// Limits (the plan is marked invalid and the caller falls back to the list-based path): the
+// members of a tile sit in more than 128 cells, or the cells around them number more than 512
+// or hold more than 8,192 particles (particles not spatially sorted); more than 2,559 staged
+// particles per tile; rows longer than the row capacity (reported back so that the caller
+// retries with longer rows, HOOMD's own protocol for its list); tilted boxes.
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+#include "azp_device.hpp"
+#include "pair_plan.hpp"
+
+namespace azp
+{
+constexpr uint32_t PC_THREADS = 256;
+constexpr uint32_t PC_BATCH = 1024;     // candidates staged at a time
+constexpr uint32_t PC_MAXCAND = 8192;   // candidates of a tile's cells (13 bits of a raw entry; 12 when they suffice)
+constexpr uint32_t PC_MAXCELLS = 512;   // distinct cells next to a tile's members
+constexpr uint32_t PC_MAXMC = 128;      // distinct cells of the members themselves
+constexpr uint32_t PC_RUNS = 18;        // 3 x 3 rows of cells, each at most two runs
+constexpr uint32_t PC_SETA = 512, PC_SETB = 1024; // hash sets: member cells, their neighbor cells
+constexpr uint32_t PC_ROWMAX = 512;     // largest row capacity + 8 (PLAN_ROWBUF)
+constexpr uint32_t PC_EMPTY = 0xffffffffu;
+constexpr uint32_t PC_CTAB = 1024;      // bins of the r^2 -> class table (one particle type)
+
+struct PlanCellsKArgs
+    {
+    const double* pos;
+    const double* rlistsq;
+    const double* rcutsq;
+    const double* rinnersq;
+    const uint32_t* cell_of;
+    const uint32_t* order;
+    const uint32_t* cell_start;
+    const uint32_t* n_excl;
+    const uint32_t* excl;
+    uint64_t excl_pitch;
+    uint32_t* n_neigh;
+    uint16_t* raw;          // n_tiles x row_cap x 256: entry k of member h of a tile at [k][h]
+    uint32_t* tile_nstage;
+    uint64_t* tile_head;
+    uint32_t* stage_idx;
+    uint32_t* slice_K;
+    uint32_t* slice_Kend;
+    uint64_t* slice_head;
+    uint4* cnl;
+    uint32_t* flags;        // [1] invalid, [2] max staged set, [3] shell width, [5] longest row, [6] reason
+    double r_list_max;
+    BoxDev box;
+    int dim[3], periodic[3];
+    uint32_t N, n_total, ntypes;
+    uint32_t row_cap;       // multiple of 8
+    uint32_t stage_stride;
+    uint32_t stop_after;    // profiling only (AZP_PLAN_CELLS_STOP): leave after this phase, the plan is then unusable
+    };
+
+// Distinct coordinates of the cells next to cell c along one axis, ascending: c - 1, c, c + 1
+// wrapped (periodic) or clipped (not periodic); an axis of up to 3 cells lists every cell once.
+__device__ __forceinline__ int axis_neighbors(int c, int dim, int periodic, int (&out)[3])
+    {
+    int n = 0;
+    if (!periodic)
+        {
+        for (int o = -1; o <= 1; ++o)
+            if (c + o >= 0 && c + o < dim)
+                out[n++] = c + o;
+        return n;
+        }
+    if (dim <= 3)
+        {
+        for (int q = 0; q < dim; ++q)
+            out[n++] = q;
+        return n;
+        }
+    int v0 = (c - 1 + dim) % dim, v1 = c, v2 = (c + 1) % dim;
+    // ascending order (at most one of the three wrapped)
+    if (v0 > v1) { const int t = v0; v0 = v1; v1 = v2; v2 = t; }       // c = 0: {dim - 1, 0, 1} -> {0, 1, dim - 1}
+    else if (v2 < v1) { const int t = v2; v2 = v1; v1 = v0; v0 = t; }  // c = dim - 1: {dim - 2, dim - 1, 0} -> {0, dim - 2, dim - 1}
+    out[0] = v0; out[1] = v1; out[2] = v2;
+    return 3;
+    }
+
+// open-addressing set in LDS; returns 1 when this call put the key in, 0 when it was there, 2 when the set is full
+__device__ __forceinline__ uint32_t set_insert(uint32_t* set, uint32_t size, uint32_t key)
+    {
+    uint32_t h = (key * 2654435761u) >> 12;
+    for (uint32_t probe = 0; probe < size; ++probe)
+        {
+        h &= size - 1u;
+        const uint32_t prev = atomicCAS(&set[h], PC_EMPTY, key);
+        if (prev == PC_EMPTY)
+            return 1u;
+        if (prev == key)
+            return 0u;
+        ++h;
+        }
+    return 2u;
+    }
+
+// class of a listed pair at separation^2 rsq (pair_plan.hip): 0 core, 1 near (inside the cutoff or
+// too close to call), 2 + s buffer shell s <=> certainly >= r_cut + s w; rcsq_m = r_cut^2 * 1.0001,
+// rcw = r_cut / w, rscale = 0.99995 / w
+__device__ __forceinline__ uint32_t pair_class(float rsq, float rcsq_m, float rin, float rcw, float rscale, float fmax_shell)
+    {
+    const float shf = floorf(__builtin_fmaf(__builtin_amdgcn_sqrtf(rsq), rscale, -rcw));
+    const uint32_t shell = 2u + (uint32_t)fminf(fmaxf(shf, 0.f), fmax_shell); // NaN (w = 0) -> shell 0
+    return !(rsq >= rcsq_m) ? ((rsq < rin) ? 0u : 1u) : shell;
+    }
+
+template<bool SINGLE> // SINGLE: one particle type (cutoffs are constants, classes come from a table)
+__global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsKArgs a)
+    {
+    // One region, reused. Phase 0: hash sets + unsorted cells. Phase 2: the candidates of the
+    // current batch (x, y, z, particle index; 16 B) + their types. Phases 3, 4: candidate -> slot.
+    // The per-thread class counters / cursors live behind it through phases 2 .. 4.
+    constexpr uint32_t CAND_BYTES = PC_BATCH * 16 + PC_BATCH; // 17,408
+    constexpr uint32_t CUR_OFF = CAND_BYTES;
+    constexpr uint32_t REGION = CUR_OFF + PLAN_CLASSES * PC_THREADS * 2; // + 5,120 = 22,528
+    static_assert(CAND_BYTES >= 2 * PC_MAXCAND, "slot table does not fit");
+    static_assert(CAND_BYTES >= (PC_SETA + PC_SETB + PC_MAXCELLS) * 4, "hash sets do not fit");
+    __shared__ __attribute__((aligned(16))) unsigned char s_region[REGION];
+    float4* cand = reinterpret_cast<float4*>(s_region);
+    unsigned char* ctype = s_region + PC_BATCH * 16;
+    uint32_t* setA = reinterpret_cast<uint32_t*>(s_region);
+    uint32_t* setB = setA + PC_SETA;
+    uint32_t* s_tmp = setB + PC_SETB;
+    uint16_t* s_slot = reinterpret_cast<uint16_t*>(s_region);
+    uint16_t* s_cur = reinterpret_cast<uint16_t*>(s_region + CUR_OFF); // [class][thread]
+    __shared__ uint32_t s_used[PC_MAXCAND / 32];
+    __shared__ uint32_t s_wordbase[PC_MAXCAND / 32 + 1];
+    uint32_t* s_cells = reinterpret_cast<uint32_t*>(s_region + 8192); // phase 1 only: the cells in ascending order
+    static_assert(8192 + PC_MAXCELLS * 4 <= CAND_BYTES, "sorted cells do not fit");
+    __shared__ uint32_t s_cfirst[PC_MAXCELLS], s_coff[PC_MAXCELLS + 8];
+    __shared__ uint32_t s_mcl[PC_MAXMC];                // the distinct cells of the members
+    __shared__ uint32_t s_runs[PC_MAXMC][PC_RUNS];      // per member cell: candidate ranges, g0 | g1 << 16
+    __shared__ unsigned char s_ctab[SINGLE ? PC_CTAB : 4];
+    __shared__ uint32_t s_kend[4][PLAN_SHELLS + 1], s_smax[4];
+    __shared__ float s_rcutsq[64], s_rinnersq[64], s_rcw[64], s_rlistsq[64];
+    __shared__ uint32_t s_wide, s_bad, s_ncells, s_nmc;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t first = tile * 256u;
+    const uint32_t count = min(256u, a.N - first);
+    const bool member = tid < count;
+    const uint32_t i = first + (member ? tid : 0u);
+    const bool rc_cached = a.ntypes <= 8;
+    const uint32_t ntp = a.ntypes * a.ntypes;
+    const int dimx = a.dim[0], dimy = a.dim[1], dimz = a.dim[2];
+
+    // shell width (as pair_plan.hip): r_buff / PLAN_SHELLS with r_buff = (r_list_max - r_cut_max) / 2
+    float shell_w = 0.f;
+        {
+        double rc_max_sq = 0.0;
+        for (uint32_t t = 0; t < ntp; ++t)
+            rc_max_sq = fmax(rc_max_sq, a.rcutsq[t]);
+        const double w = (a.r_list_max > 0.0) ? 0.5 * (a.r_list_max - sqrt(rc_max_sq)) / PLAN_SHELLS : 0.0;
+        shell_w = (w > 0.0) ? (float)w : 0.f;
+        if (blockIdx.x == 0 && tid == 0)
+            a.flags[3] = (uint32_t)__float_as_int(shell_w);
+        }
+    const float shell_winv = (shell_w > 0.f) ? 1.0f / shell_w : 0.f;
+    const float rscale = 0.99995f * shell_winv;
+
+    // ---- phase 0: members, their cells, the set of cells next to them ----
+    if (tid < 4)
+        {
+        s_smax[tid] = 0;
+        for (uint32_t sh = 0; sh <= PLAN_SHELLS; ++sh)
+            s_kend[tid][sh] = 0;
+        }
+    if (tid == 0)
+        {
+        s_wide = 0;
+        s_bad = 0;
+        s_ncells = 0;
+        s_nmc = 0;
+        }
+    for (uint32_t t = tid; t < PC_MAXCAND / 32; t += PC_THREADS)
+        s_used[t] = 0;
+    for (uint32_t t = tid; t < PC_SETA + PC_SETB; t += PC_THREADS)
+        setA[t] = PC_EMPTY;
+    if (!SINGLE && rc_cached && tid < ntp)
+        {
+        s_rcutsq[tid] = (float)a.rcutsq[tid] * 1.0001f;
+        s_rinnersq[tid] = a.rinnersq ? (float)a.rinnersq[tid] : 0.f;
+        s_rcw[tid] = sqrtf(fmaxf((float)a.rcutsq[tid], 0.f)) * shell_winv;
+        // single-precision test with a margin: a superset of the exact list (r^2 <= r_list^2)
+        s_rlistsq[tid] = a.rlistsq[tid] > 0.0 ? (float)a.rlistsq[tid] * 1.00001f : -1.f;
+        }
+    const double3 cref = load_scalar3_of4(a.pos, first);
+    __syncthreads();
+    float xi = 0.f, yi = 0.f, zi = 0.f;
+    uint32_t mytype = 0, mycell = 0;
+    if (member)
+        {
+        const double4 p = load_scalar4(a.pos, i);
+        double x = p.x - cref.x, y = p.y - cref.y, z = p.z - cref.z;
+        // orthorhombic boxes only (the host refuses tilted ones)
+        if (a.box.px) x = __builtin_fma(-a.box.Lx, rint(x * a.box.Lxinv), x);
+        if (a.box.py) y = __builtin_fma(-a.box.Ly, rint(y * a.box.Lyinv), y);
+        if (a.box.pz) z = __builtin_fma(-a.box.Lz, rint(z * a.box.Lzinv), z);
+        // the staged images are minimum images for every member only if the tile and its
+        // list radius fit into half the box (as in the force kernel); else re-image pairs
+        if (!(a.r_list_max > 0.0) || (a.box.px && fabs(x) + a.r_list_max >= 0.5 * a.box.Lx)
+            || (a.box.py && fabs(y) + a.r_list_max >= 0.5 * a.box.Ly) || (a.box.pz && fabs(z) + a.r_list_max >= 0.5 * a.box.Lz))
+            s_wide = 1;
+        xi = (float)x; yi = (float)y; zi = (float)z;
+        mytype = (uint32_t)type_from_w(p.w);
+        mycell = a.cell_of[i];
+        if (set_insert(setA, PC_SETA, mycell) == 1u)
+            {
+            // first member seen in this cell: its neighbor cells join the tile's cell set
+            const uint32_t imc = atomicAdd(&s_nmc, 1u);
+            if (imc < PC_MAXMC)
+                s_mcl[imc] = mycell;
+            const int ccx = (int)(mycell % (uint32_t)dimx), ccy = (int)((mycell / (uint32_t)dimx) % (uint32_t)dimy), ccz = (int)(mycell / (uint32_t)(dimx * dimy));
+            int nzs[3], nys[3], nxs[3];
+            const int cz_n = axis_neighbors(ccz, dimz, a.periodic[2], nzs), cy_n = axis_neighbors(ccy, dimy, a.periodic[1], nys);
+            const int cx_n = axis_neighbors(ccx, dimx, a.periodic[0], nxs);
+            for (int qz = 0; qz < 3; ++qz)
+                for (int qy = 0; qy < 3; ++qy)
+                    for (int qx = 0; qx < 3; ++qx)
+                        {
+                        if (qz >= cz_n || qy >= cy_n || qx >= cx_n || imc >= PC_MAXMC || *(volatile uint32_t*)&s_ncells > PC_MAXCELLS)
+                            continue; // (beyond a limit: particles not sorted, stop filling the set)
+                        const uint32_t nc = (uint32_t)((nzs[qz] * dimy + nys[qy]) * dimx + nxs[qx]);
+                        const uint32_t r = set_insert(setB, PC_SETB, nc);
+                        if (r == 1u)
+                            {
+                            const uint32_t idx = atomicAdd(&s_ncells, 1u);
+                            if (idx < PC_MAXCELLS)
+                                s_tmp[idx] = nc;
+                            }
+                        else if (r == 2u)
+                            atomicAdd(&s_ncells, PC_MAXCELLS + 1u);
+                        }
+            }
+        }
+    __syncthreads();
+    const uint32_t ncell_blk = s_ncells, n_mc = s_nmc;
+    if (ncell_blk > PC_MAXCELLS || n_mc > PC_MAXMC)
+        {
+        if (tid == 0)
+            {
+            atomicOr(&a.flags[1], 1u);
+            atomicMax(&a.flags[6], 4u); // members spread over too many cells: particles not spatially sorted
+            a.tile_nstage[tile] = 0;
+            a.tile_head[tile] = (uint64_t)tile * a.stage_stride;
+            }
+        return;
+        }
+    // ---- phase 1: the cells in ascending order, candidate ranges, the runs of every member cell ----
+    for (uint32_t t = tid; t < ncell_blk; t += PC_THREADS)
+        {
+        const uint32_t c = s_tmp[t];
+        uint32_t rank = 0;
+        for (uint32_t u = 0; u < ncell_blk; ++u)
+            rank += (s_tmp[u] < c) ? 1u : 0u;
+        const uint32_t f = a.cell_start[c];
+        s_cells[rank] = c;
+        s_cfirst[rank] = f;
+        s_coff[rank + 1] = a.cell_start[c + 1] - f;
+        }
+    __syncthreads();
+    if (tid < 64)
+        {
+        // inclusive scan of up to 512 counts, 8 per lane
+        constexpr uint32_t PER = PC_MAXCELLS / 64;
+        uint32_t v[PER], sum = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < PER; ++q)
+            {
+            const uint32_t t = tid * PER + q;
+            v[q] = (t < ncell_blk) ? s_coff[t + 1] : 0u;
+            sum += v[q];
+            }
+        uint32_t incl = sum;
+        for (int off = 1; off < 64; off <<= 1)
+            {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+            if ((int)lane >= off)
+                incl += up;
+            }
+        uint32_t acc = incl - sum;
+#pragma unroll
+        for (uint32_t q = 0; q < PER; ++q)
+            {
+            const uint32_t t = tid * PER + q;
+            acc += v[q];
+            if (t < ncell_blk)
+                s_coff[t + 1] = acc;
+            }
+        if (tid == 0)
+            s_coff[0] = 0;
+        }
+    __syncthreads();
+    const uint32_t NC = s_coff[ncell_blk];
+    if (NC > PC_MAXCAND)
+        {
+        if (tid == 0)
+            {
+            atomicOr(&a.flags[1], 1u);
+            atomicMax(&a.flags[6], 5u); // too many particles in the cells around the tile
+            a.tile_nstage[tile] = 0;
+            a.tile_head[tile] = (uint64_t)tile * a.stage_stride;
+            }
+        return;
+        }
+    // a raw entry: candidate number | class. 4 bits of class (core, near, 8 shells) when 12 bits hold the
+    // candidate number; else 3 (shells 5, 6, 7 are filed under 5 -- conservative, a shell is a lower bound)
+    const uint32_t cbits = (NC <= 4096u) ? 4u : 3u;
+    const uint32_t cmask = (1u << cbits) - 1u;
+    const float fmax_shell = (cbits == 4u) ? (float)(PLAN_SHELLS - 1u) : 5.f;
+    const float rl1 = SINGLE ? (a.rlistsq[0] > 0.0 ? (float)a.rlistsq[0] * 1.00001f : -1.f) : 0.f;
+    // the runs of a member cell: its 3 x 3 rows of cells along x; a row is one or two runs of consecutive
+    // cells, consecutive in the sorted cell array too (every one of them is in the set): one contiguous
+    // candidate range per run
+    for (uint32_t t = tid; t < n_mc * PC_RUNS; t += PC_THREADS)
+        {
+        const uint32_t imc = t / PC_RUNS, q = t % PC_RUNS;
+        const uint32_t mc = s_mcl[imc];
+        const int mcx = (int)(mc % (uint32_t)dimx), mcy = (int)((mc / (uint32_t)dimx) % (uint32_t)dimy), mcz = (int)(mc / (uint32_t)(dimx * dimy));
+        int nzs[3], nys[3], nxs[3];
+        const int cz_n = axis_neighbors(mcz, dimz, a.periodic[2], nzs), cy_n = axis_neighbors(mcy, dimy, a.periodic[1], nys);
+        const int cx_n = axis_neighbors(mcx, dimx, a.periodic[0], nxs);
+        int run0[2] = {0, 0}, runlen[2] = {0, 0};
+        int nruns = 0;
+        for (int k = 0; k < 3; ++k)
+            {
+            if (k >= cx_n)
+                continue;
+            if (nruns && nxs[k] == run0[nruns - 1] + runlen[nruns - 1])
+                ++runlen[nruns - 1];
+            else
+                {
+                run0[nruns] = nxs[k];
+                runlen[nruns] = 1;
+                ++nruns;
+                }
+            }
+        const int row = (int)(q >> 1), r = (int)(q & 1u);
+        const int qz = row / 3, qy = row % 3;
+        uint32_t packed = 0; // empty run
+        if (qz < cz_n && qy < cy_n && r < nruns)
+            {
+            const int zz = qz == 0 ? nzs[0] : (qz == 1 ? nzs[1] : nzs[2]);
+            const int yy = qy == 0 ? nys[0] : (qy == 1 ? nys[1] : nys[2]);
+            const uint32_t c = (uint32_t)((zz * dimy + yy) * dimx + (r ? run0[1] : run0[0]));
+            uint32_t sl = 0, sh = ncell_blk; // s_cells[sl] == c (present by construction)
+            while (sh - sl > 1)
+                {
+                const uint32_t mid = (sl + sh) >> 1;
+                if (s_cells[mid] <= c) sl = mid; else sh = mid;
+                }
+            packed = s_coff[sl] | (s_coff[sl + (uint32_t)(r ? runlen[1] : runlen[0])] << 16); // NC <= 8192: 16 bits each
+            }
+        s_runs[imc][q] = packed;
+        }
+    if (SINGLE)
+        {
+        // r^2 -> class, at the lower edge of each bin (classes grow with r: never too high a class)
+        const float rcsq_m = (float)a.rcutsq[0] * 1.0001f, rin = a.rinnersq ? (float)a.rinnersq[0] : 0.f;
+        const float rcw = sqrtf(fmaxf((float)a.rcutsq[0], 0.f)) * shell_winv;
+        for (uint32_t t = tid; t < PC_CTAB; t += PC_THREADS)
+            {
+            const float lo = (float)t * (rl1 * (1.0f / PC_CTAB)) * 0.999999f;
+            s_ctab[t] = (unsigned char)pair_class(lo, rcsq_m, rin, rcw, rscale, fmax_shell);
+            }
+        }
+    // which member cell is mine
+    uint32_t imc_mine = 0;
+    for (uint32_t u = 0; u < n_mc; ++u)
+        imc_mine = (s_mcl[u] == mycell) ? u : imc_mine;
+    const bool wide = s_wide != 0;
+    const float bLx = (float)a.box.Lx, bLy = (float)a.box.Ly, bLz = (float)a.box.Lz;
+    // (1 / L = 0 along a non-periodic axis: rint(0) = 0, nothing is subtracted)
+    const float bLxi = a.box.px ? (float)a.box.Lxinv : 0.f, bLyi = a.box.py ? (float)a.box.Lyinv : 0.f, bLzi = a.box.pz ? (float)a.box.Lzinv : 0.f;
+    const float tscale = SINGLE && rl1 > 0.f ? (float)PC_CTAB / rl1 : 0.f;
+    uint16_t* raw_tile = a.raw + (uint64_t)tile * 256u * a.row_cap;
+    const uint32_t trow = mytype * a.ntypes;
+    const uint32_t nex = (a.n_excl && member) ? a.n_excl[i] : 0u;
+    if (a.stop_after == 1u)
+        return;
+
+    // ---- phase 2: stage a batch of candidates; every thread walks its member's runs through it ----
+    uint32_t cnt = 0;
+    for (uint32_t t = 0; t < PLAN_CLASSES; ++t)
+        s_cur[t * PC_THREADS + tid] = 0;
+    for (uint32_t b0 = 0; b0 < NC; b0 += PC_BATCH)
+        {
+        const uint32_t nbat = min(PC_BATCH, NC - b0);
+        __syncthreads(); // previous batch (first pass: the hash sets, the run table) settled
+        for (uint32_t t = tid; t < nbat; t += PC_THREADS)
+            {
+            const uint32_t g = b0 + t;
+            uint32_t sl = 0, sh = ncell_blk; // cell s with coff[s] <= g < coff[s + 1]
+            while (sh - sl > 1)
+                {
+                const uint32_t mid = (sl + sh) >> 1;
+                if (s_coff[mid] <= g) sl = mid; else sh = mid;
+                }
+            const uint32_t j = a.order[s_cfirst[sl] + (g - s_coff[sl])];
+            const double4 pj = load_scalar4(a.pos, j);
+            double x = pj.x - cref.x, y = pj.y - cref.y, z = pj.z - cref.z;
+            if (a.box.px) x = __builtin_fma(-a.box.Lx, rint(x * a.box.Lxinv), x);
+            if (a.box.py) y = __builtin_fma(-a.box.Ly, rint(y * a.box.Lyinv), y);
+            if (a.box.pz) z = __builtin_fma(-a.box.Lz, rint(z * a.box.Lzinv), z);
+            cand[t] = make_float4((float)x, (float)y, (float)z, __int_as_float((int)j));
+            if (!SINGLE)
+                ctype[t] = (unsigned char)type_from_w(pj.w);
+            }
+        __syncthreads();
+        if (member)
+            {
+            uint32_t q = 0, g = 0, l1 = 0;
+            for (;;)
+                {
+                while (g >= l1 && q < PC_RUNS)
+                    {
+                    const uint32_t packed = s_runs[imc_mine][q++];
+                    g = max(packed & 0xffffu, b0);
+                    l1 = min(packed >> 16, b0 + nbat);
+                    }
+                if (g >= l1)
+                    break;
+                const uint32_t c = g - b0;
+                const float4 cv = cand[c];
+                float dx = xi - cv.x, dy = yi - cv.y, dz = zi - cv.z;
+                if (wide)
+                    {
+                    dz = __builtin_fmaf(-bLz, rintf(dz * bLzi), dz);
+                    dy = __builtin_fmaf(-bLy, rintf(dy * bLyi), dy);
+                    dx = __builtin_fmaf(-bLx, rintf(dx * bLxi), dx);
+                    }
+                const float rsq = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                uint32_t tp = 0;
+                float rl = rl1;
+                if (!SINGLE)
+                    {
+                    tp = trow + ctype[c];
+                    rl = rc_cached ? s_rlistsq[tp] : (a.rlistsq[tp] > 0.0 ? (float)a.rlistsq[tp] * 1.00001f : -1.f);
+                    }
+                if (rsq <= rl) // rl < 0: the type pair is not listed
+                    {
+                    const uint32_t j = (uint32_t)__float_as_int(cv.w);
+                    bool acc = j != i;
+                    for (uint32_t e = 0; e < nex; ++e)
+                        acc = acc && (a.excl[(uint64_t)e * a.excl_pitch + i] != j);
+                    if (acc)
+                        {
+                        uint32_t cls;
+                        if (SINGLE)
+                            cls = s_ctab[min((uint32_t)(rsq * tscale), PC_CTAB - 1u)];
+                        else
+                            {
+                            const float rcsq_m = rc_cached ? s_rcutsq[tp] : (float)a.rcutsq[tp] * 1.0001f;
+                            const float rin = rc_cached ? s_rinnersq[tp] : (a.rinnersq ? (float)a.rinnersq[tp] : 0.f);
+                            const float rcw = rc_cached ? s_rcw[tp] : sqrtf(fmaxf((float)a.rcutsq[tp], 0.f)) * shell_winv;
+                            cls = pair_class(rsq, rcsq_m, rin, rcw, rscale, fmax_shell);
+                            }
+                        if (cnt < a.row_cap)
+                            raw_tile[cnt * 256u + tid] = (uint16_t)((g << cbits) | cls);
+                        ++cnt;
+                        ++s_cur[cls * PC_THREADS + tid];
+                        atomicOr(&s_used[g >> 5], 1u << (g & 31u));
+                        }
+                    }
+                ++g;
+                }
+            }
+        }
+    __syncthreads();
+    if (a.stop_after == 2u)
+        return;
+    // ---- phase 3: row lengths; slot numbers = rank among the marked candidates; stage list ----
+    if (member)
+        {
+        a.n_neigh[i] = cnt;
+        if (cnt > a.row_cap)
+            {
+            atomicOr(&a.flags[1], 1u);
+            atomicMax(&a.flags[6], 3u); // row longer than the capacity: the caller retries with longer rows
+            s_bad = 1;
+            }
+        }
+    uint32_t longest = member ? cnt : 0u;
+    for (int off = 32; off > 0; off >>= 1)
+        longest = max(longest, (uint32_t)__shfl_xor((int)longest, off, 64));
+    if (lane == 0)
+        {
+        s_smax[wave] = longest; // the four waves are the force kernel's four slices
+        atomicMax(&a.flags[5], longest);
+        }
+    if (tid < 64)
+        {
+        // exclusive scan of the popcounts of the bitmap words, four per lane
+        constexpr uint32_t PER = PC_MAXCAND / 32 / 64;
+        uint32_t w[PER], sum = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < PER; ++q)
+            {
+            w[q] = (uint32_t)__popc(s_used[PER * tid + q]);
+            sum += w[q];
+            }
+        uint32_t incl = sum;
+        for (int off = 1; off < 64; off <<= 1)
+            {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, off, 64);
+            if ((int)lane >= off)
+                incl += v;
+            }
+        uint32_t acc = incl - sum;
+#pragma unroll
+        for (uint32_t q = 0; q < PER; ++q)
+            {
+            s_wordbase[PER * tid + q] = acc;
+            acc += w[q];
+            }
+        if (tid == 63)
+            s_wordbase[PC_MAXCAND / 32] = incl;
+        }
+    __syncthreads();
+    const uint32_t n_stage = s_wordbase[PC_MAXCAND / 32];
+    const bool bad = s_bad || n_stage > PLAN_MAX_STAGE || n_stage > a.stage_stride;
+    if (tid == 0)
+        {
+        a.tile_nstage[tile] = bad ? 0u : n_stage;
+        a.tile_head[tile] = (uint64_t)tile * a.stage_stride;
+        atomicMax(&a.flags[2], n_stage);
+        if (n_stage > PLAN_MAX_STAGE || n_stage > a.stage_stride)
+            {
+            atomicOr(&a.flags[1], 1u);
+            atomicMax(&a.flags[6], 2u);
+            }
+        }
+    if (bad)
+        return;
+    uint32_t* stage = a.stage_idx + (uint64_t)tile * a.stage_stride;
+    for (uint32_t g = tid; g < NC; g += PC_THREADS)
+        {
+        const uint32_t w = s_used[g >> 5], bit = 1u << (g & 31u);
+        if (w & bit)
+            {
+            const uint32_t slot = s_wordbase[g >> 5] + (uint32_t)__popc(w & (bit - 1u));
+            s_slot[g] = (uint16_t)slot;
+            uint32_t sl = 0, sh = ncell_blk;
+            while (sh - sl > 1)
+                {
+                const uint32_t mid = (sl + sh) >> 1;
+                if (s_coff[mid] <= g) sl = mid; else sh = mid;
+                }
+            stage[slot] = a.order[s_cfirst[sl] + (g - s_coff[sl])];
+            }
+        }
+    // class totals -> first row position of each class (the cursors of phase 4); chunk counts per class boundary
+    const uint32_t n = member ? cnt : 0u;
+    uint32_t before = 0;
+    for (uint32_t c = 0; c < PLAN_CLASSES; ++c)
+        {
+        const uint32_t v = s_cur[c * PC_THREADS + tid];
+        s_cur[c * PC_THREADS + tid] = (uint16_t)before;
+        before += v;
+        if (c >= 1u && member)
+            atomicMax(&s_kend[wave][c - 1u], (before + 7u) / 8u); // [0]: through "near", [1 + s]: through shell s
+        }
+    __syncthreads();
+    if (a.stop_after == 4u)
+        return;
+    // ---- phase 4: raw rows -> compiled rows (class by class, 16-byte chunks in the force kernel's lane order) ----
+    const uint32_t Kcap = a.row_cap / 8u;
+    const uint32_t slice = tile * 4u + wave;
+    const uint32_t K = (s_smax[wave] + 7u) / 8u;
+    unsigned char* out = reinterpret_cast<unsigned char*>(a.cnl + (uint64_t)slice * Kcap * 64ull) + lane * 16u;
+    for (uint32_t c = n >> 3; c < K; ++c) // the tail of the row up to the slice's rectangle: dummy slots
+        *reinterpret_cast<uint4*>(out + c * 1024u) = make_uint4(0, 0, 0, 0);
+    for (uint32_t k = 0; k < n; ++k)
+        {
+        const uint32_t e = raw_tile[k * 256u + tid];
+        const uint32_t cls = e & cmask;
+        const uint32_t off = ((uint32_t)s_slot[e >> cbits] + 1u) * 8u;
+        const uint32_t posn = s_cur[cls * PC_THREADS + tid];
+        s_cur[cls * PC_THREADS + tid] = (uint16_t)(posn + 1u);
+        *reinterpret_cast<uint16_t*>(out + (posn >> 3) * 1024u + (posn & 7u) * 2u) = (uint16_t)off;
+        }
+    if (lane == 0)
+        {
+        a.slice_K[slice] = K;
+        a.slice_head[slice] = (uint64_t)slice * Kcap;
+        for (uint32_t sh = 0; sh <= PLAN_SHELLS; ++sh)
+            a.slice_Kend[(PLAN_SHELLS + 1) * slice + sh] = s_kend[wave][sh];
+        }
+    }
+
+#define AZP_HIP_TRY(expr)                      \
+    do                                         \
+        {                                      \
+        hipError_t e_ = (expr);                \
+        if (e_ != hipSuccess) return (int)e_;  \
+        } while (0)
+
+template<class T> static hipError_t ensure_buf(T*& ptr, size_t& cap, size_t need)
+    {
+    if (need <= cap && ptr)
+        return hipSuccess;
+    if (ptr)
+        {
+        hipError_t e = hipFree(ptr);
+        if (e != hipSuccess) return e;
+        ptr = nullptr;
+        }
+    const size_t newcap = need + need / 8 + 64;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&ptr), newcap * sizeof(T));
+    cap = (e == hipSuccess) ? newcap : 0;
+    return e;
+    }
+
+int plan_build_from_cells(PairPlan& p, const azp_nlist_args& c, const azp_pair_args& pa, hipStream_t s)
+    {
+    p.valid = false;
+    p.invalid_reason = 0;
+    p.from_cells = true;
+    p.N = c.N;
+    p.n_max = c.n_total;
+    p.size_nlist = 0;
+    ++p.builds;
+    if (c.N == 0)
+        return AZP_SUCCESS;
+    if (c.box.tilt[0] != 0.0 || c.box.tilt[1] != 0.0 || c.box.tilt[2] != 0.0 || c.ntypes > 255)
+        {
+        p.invalid_reason = 6; // cells of a tilted box are not binned by azp_nlist_cell_assign either; types are staged as bytes
+        return AZP_SUCCESS;
+        }
+    uint32_t row_cap = c.row_capacity ? c.row_capacity : 160u;
+    row_cap = std::min<uint32_t>((row_cap + 7u) & ~7u, PC_ROWMAX - 8u);
+    p.tpp = 1;
+    p.tile = 256;
+    p.n_tiles = (c.N + 255u) / 256u;
+    p.n_slices = p.n_tiles * 4;
+    p.row_cap = row_cap;
+    size_t cap_heads_t = p.d_tile_head ? p.cap_tiles : 0, cap_heads_s = p.d_slice_head ? p.cap_slices : 0;
+    AZP_HIP_TRY(ensure_buf(p.d_tile_nstage, p.cap_tiles, p.n_tiles));
+    AZP_HIP_TRY(ensure_buf(p.d_tile_head, cap_heads_t, p.n_tiles));
+    AZP_HIP_TRY(ensure_buf(p.d_slice_K, p.cap_slices, p.n_slices));
+    AZP_HIP_TRY(ensure_buf(p.d_slice_Kend, p.cap_kend, (PLAN_SHELLS + 1) * (size_t)p.n_slices));
+    AZP_HIP_TRY(ensure_buf(p.d_slice_head, cap_heads_s, p.n_slices));
+    size_t cap_flags = p.d_flags ? 8 : 0;
+    AZP_HIP_TRY(ensure_buf(p.d_flags, cap_flags, 8));
+    p.total_chunks = (uint64_t)p.n_slices * (row_cap / 8u);
+    AZP_HIP_TRY(ensure_buf(p.d_cnl, p.cap_cnl, (size_t)p.total_chunks * 64));
+    AZP_HIP_TRY(ensure_buf(p.d_raw, p.cap_raw, (size_t)p.n_tiles * 256u * row_cap));
+
+    PlanCellsKArgs k;
+    k.pos = c.d_pos;
+    k.rlistsq = c.d_rlistsq;
+    k.rcutsq = pa.d_rcutsq;
+    k.rinnersq = pa.d_rinnersq;
+    k.cell_of = c.d_cell_of;
+    k.order = c.d_order;
+    k.cell_start = c.d_cell_start;
+    k.n_excl = c.d_n_excl;
+    k.excl = c.d_excl;
+    k.excl_pitch = c.excl_pitch;
+    k.n_neigh = c.d_n_neigh;
+    k.raw = p.d_raw;
+    k.tile_nstage = p.d_tile_nstage;
+    k.tile_head = p.d_tile_head;
+    k.slice_K = p.d_slice_K;
+    k.slice_Kend = p.d_slice_Kend;
+    k.slice_head = p.d_slice_head;
+    k.cnl = p.d_cnl;
+    k.flags = p.d_flags;
+    k.r_list_max = pa.r_list_max;
+    k.box = make_box_dev(c.box);
+    for (int q = 0; q < 3; ++q)
+        {
+        k.dim[q] = (int)c.grid.dim[q];
+        k.periodic[q] = c.grid.periodic[q];
+        }
+    k.N = c.N;
+    k.n_total = c.n_total;
+    k.ntypes = c.ntypes;
+    k.row_cap = row_cap;
+    static const uint32_t stop_after = []() { const char* e = getenv("AZP_PLAN_CELLS_STOP"); return e ? (uint32_t)atoi(e) : 0u; }();
+    k.stop_after = stop_after;
+
+    uint32_t stride = p.stage_stride_hint;
+    if (stride == 0)
+        stride = ((uint64_t)p.n_tiles * (PLAN_MAX_STAGE + 1) * 4 <= (256ull << 20)) ? PLAN_MAX_STAGE + 1 : 1536;
+    uint32_t h_flags[8];
+    for (;;)
+        {
+        stride = std::min<uint32_t>((stride + 63u) & ~63u, PLAN_MAX_STAGE + 1);
+        AZP_HIP_TRY(ensure_buf(p.d_stage_idx, p.cap_stage, (size_t)p.n_tiles * stride));
+        AZP_HIP_TRY(hipMemsetAsync(p.d_flags, 0, 8 * sizeof(uint32_t), s));
+        k.stage_idx = p.d_stage_idx;
+        k.stage_stride = stride;
+        if (c.ntypes == 1)
+            hipLaunchKernelGGL(plan_cells_kernel<true>, dim3(p.n_tiles), dim3(PC_THREADS), 0, s, k);
+        else
+            hipLaunchKernelGGL(plan_cells_kernel<false>, dim3(p.n_tiles), dim3(PC_THREADS), 0, s, k);
+        AZP_HIP_TRY(hipGetLastError());
+        AZP_HIP_TRY(hipMemcpyAsync(h_flags, p.d_flags, sizeof(h_flags), hipMemcpyDeviceToHost, s));
+        p.h_tile_nstage.resize(p.n_tiles);
+        AZP_HIP_TRY(hipMemcpyAsync(p.h_tile_nstage.data(), p.d_tile_nstage, sizeof(uint32_t) * p.n_tiles, hipMemcpyDeviceToHost, s));
+        AZP_HIP_TRY(hipStreamSynchronize(s));
+        p.max_stage = h_flags[2];
+        p.max_row = h_flags[5];
+        if (stop_after)
+            {
+            p.invalid_reason = 7; // profiling run: the kernel left early, nothing to use
+            return AZP_SUCCESS;
+            }
+        if (!h_flags[1])
+            break;
+        if (h_flags[6] == 2 && p.max_stage <= PLAN_MAX_STAGE && stride < PLAN_MAX_STAGE + 1)
+            {
+            stride = p.max_stage + p.max_stage / 8 + 64; // the stride was the problem: grow and redo
+            continue;
+            }
+        p.invalid_reason = (int)h_flags[6]; // 2 stage set, 3 row capacity (max_row says how long), 4 / 5 cell block
+        return AZP_SUCCESS;
+        }
+    p.stage_stride_hint = p.max_stage + p.max_stage / 16 + 32;
+    p.total_stage = (uint64_t)p.n_tiles * stride;
+        {
+        float fm;
+        __builtin_memcpy(&fm, &h_flags[3], sizeof(fm));
+        p.shell_width = fm;
+        }
+    p.cap = plan_cap_for(p.max_stage);
+    // identity of "the list" for the planned entry points: the plan's own raw rows and slice heads
+    p.nlist_ptr = reinterpret_cast<const uint32_t*>(p.d_raw);
+    p.head_ptr = p.d_slice_head;
+    p.valid = true;
+    return AZP_SUCCESS;
+    }
+} // namespace azp
+
+extern "C" int azp_pair_plan_build_from_cells(azp_pair_plan* plan, const azp_nlist_args* cells, const azp_pair_args* pair, void* stream)
+    {
+    if (!plan || !cells || !pair || !cells->d_pos || !cells->d_rlistsq || !cells->d_cell_of || !cells->d_order || !cells->d_cell_start
+        || !cells->d_n_neigh || !pair->d_rcutsq || cells->ntypes == 0 || cells->ntypes != pair->ntypes || cells->n_total < cells->N)
+        return AZP_ERROR_INVALID_ARGUMENT;
+    for (int k = 0; k < 3; ++k)
+        if (cells->grid.dim[k] == 0)
+            return AZP_ERROR_INVALID_ARGUMENT;
+    return azp::plan_build_from_cells(*reinterpret_cast<azp::PairPlan*>(plan), *cells, *pair, static_cast<hipStream_t>(stream));
+    }

@@ -627,8 +627,8 @@ int launch_pair_planned(azp_pair_plan* plan_, const azp_pair_args* args, const t
     // a plan compiled from a different list is a caller bug, not a fallback case
     if (plan.builds == 0 || plan.N != args->N || plan.nlist_ptr != args->d_nlist || plan.head_ptr != args->d_head_list)
         return AZP_ERROR_INVALID_ARGUMENT;
-    if (!plan.valid)
-        return launch_pair<E>(args, d_params, stream);
+    if (!plan.valid) // (a plan compiled from the cell list has no HOOMD-format list to fall back to)
+        return plan.from_cells ? AZP_ERROR_INVALID_ARGUMENT : launch_pair<E>(args, d_params, stream);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool single = (args->ntypes == 1);
     if (args->compute_virial)

@@ -21,15 +21,22 @@ class NeighborList:
         self.exclusions = tuple(exclusions)
         self._consumers = []
         self.n_neigh = None
-        self.head_list = None
-        self.nlist = None
-        self.size = 0
+        self._head_list = None
+        self._nlist = None
+        self._size = 0
         self._built_generation = None
         self.num_builds = 0
-        self.n_pairs = 0          # listed pairs = sum(n_neigh)
-        self.max_neigh = 0
+        self._n_pairs = 0         # listed pairs = sum(n_neigh)
+        self._max_neigh = 0
         self._row_capacity = 0    # > 0: rows of fixed capacity (single-pass rebuilds)
         self.single_pass = True
+        # fused = True: when the list has ONE consumer and that consumer runs the tile kernels, no
+        # HOOMD-format list is built at all -- the consumer compiles its tile plan straight from
+        # the binned particles (azp_pair_plan_build_from_cells); nlist / head_list are then filled
+        # in lazily if something asks for them
+        self.fused = True
+        self._fused_active = False
+        self._stats_known = True
         self._consumer_version = 0        # bumped when a consumer's r_cut matrix changes
         self._built_consumer_version = None
         # domain-decomposed runs (azplugins_amd.domain): the rebuild decision is collective
@@ -54,6 +61,51 @@ class NeighborList:
             rc = np.maximum(rc, f._r_cut_matrix())
         return rc
 
+    # -- the HOOMD-format arrays; in fused mode they are built on first use ------------
+    @property
+    def nlist(self):
+        self._materialize()
+        return self._nlist
+
+    @property
+    def head_list(self):
+        self._materialize()
+        return self._head_list
+
+    @property
+    def size(self):
+        self._materialize()
+        return self._size
+
+    def _materialize(self):
+        pass
+
+    def _stats(self):
+        if not self._stats_known and self.n_neigh is not None:
+            import torch
+
+            if self._fused_active and not getattr(self, "_fused_counts_ready", False):
+                self._materialize()  # nobody has compiled a plan from the cells yet: count the classic way
+                return
+
+            n = self.n_neigh.to(torch.int64)
+            self._max_neigh, self._n_pairs = (int(v) for v in torch.stack([n.max(), n.sum()]).tolist()) if n.numel() else (0, 0)
+            self._stats_known = True
+
+    @property
+    def n_pairs(self):
+        self._stats()
+        return self._n_pairs
+
+    @property
+    def max_neigh(self):
+        self._stats()
+        return self._max_neigh
+
+    @property
+    def built(self):
+        return self.n_neigh is not None
+
     @property
     def r_list_max(self):
         """Upper bound on the separation of any listed pair between rebuilds."""
@@ -76,7 +128,7 @@ class Cell(NeighborList):
             force = True  # the particles were re-indexed (ParticleSorter): every stored index is stale
         if self._built_consumer_version != self._consumer_version:
             force = True  # built for another r_cut matrix
-        if not force and self.nlist is not None:
+        if not force and self.built:
             if self._built_generation == state.position_generation:
                 return
             moved = self._moved_too_far(state)
@@ -120,7 +172,7 @@ class Cell(NeighborList):
         """Benchmark / replay hook: the caller vouches that the current positions are within
         ``bound`` of the positions the list was built for (e.g. a stored snapshot of a run whose
         distance check returned exactly that), so no distance check runs for them."""
-        if self.nlist is None:
+        if not self.built:
             raise _lib.AzpError("assume_displacement: the list has not been built")
         self._built_generation = state.position_generation
         self._disp, self._disp_generation = float(bound), state.position_generation
@@ -186,10 +238,65 @@ class Cell(NeighborList):
 
         n_neigh = torch.empty(N, dtype=torch.int32, device=dev)
         a.d_n_neigh = n_neigh.data_ptr()
+        self.n_neigh = n_neigh
+        self._cells = a
+        self._keep = (rlistsq, cell_of, cell_sorted, order, cell_start, keep)
+        self._pos_at_build = state.pos[:n_total].clone()
+        self._nlist, self._head_list, self._size = None, None, 0
+        self._fused_active = self._fused_eligible()
+        self._fused_counts_ready = False
+        if self._fused_active:
+            self._stats_known = False  # row lengths come from the consumer's plan compile
+        else:
+            self._fill(stream)
+        self._order_generation = getattr(state, "order_generation", 0)
+        self._built_consumer_version = self._consumer_version
+        self._disp, self._disp_generation = 0.0, state.position_generation
+        self.num_builds += 1
+
+    def _fused_eligible(self):
+        if not self.fused or getattr(self, "_compact", False) or len(self._consumers) != 1:
+            return False
+        c = self._consumers[0]
+        return bool(getattr(c, "use_plan", False) and getattr(c, "_planned_entry", None)
+                    and getattr(c, "threads_per_particle", 0) in (0, 1) and getattr(c, "use_fused_plan", True))
+
+    def cells_args(self, row_capacity):
+        """The binned particles of the last build as azp_nlist_args (fused plan compile). Positions:
+        the ones the bins were made from."""
+        a = self._cells
+        a.d_pos = self._pos_at_build.data_ptr()
+        a.row_capacity = int(row_capacity)
+        return a
+
+    def leave_fused_mode(self):
+        """The consumer could not compile its plan from the cells (unsorted particles, very long
+        rows): build the HOOMD-format list for this build after all."""
+        if self._fused_active:
+            self._fused_active = False
+            self._materialize()
+
+    def _materialize(self):
+        if self._nlist is None and self.n_neigh is not None:
+            import torch
+
+            a = self._cells
+            a.d_pos = self._pos_at_build.data_ptr()
+            self._fill(torch.cuda.current_stream(self._pos_at_build.device).cuda_stream)
+
+    def _fill(self, stream):
+        """HOOMD-format rows from the binned particles (self._cells)."""
+        import torch
+
+        l = _lib.lib()
+        a = self._cells
+        N = a.N
+        n_neigh = self.n_neigh
+        dev = n_neigh.device
         done = False
         cap = self._row_capacity
         if self.single_pass and cap > 0 and N and not getattr(self, "_compact", False):
-            head = torch.arange(N, dtype=torch.int64, device=dev) * cap
+            head = self._head_cache(N, cap, dev)
             size = N * cap
             nlist = torch.empty(size, dtype=torch.int32, device=dev)
             flag = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -212,14 +319,17 @@ class Cell(NeighborList):
             a.d_head_list = head.data_ptr()
             a.d_nlist = nlist.data_ptr()
             _lib.check(l.azp_nlist_fill(C.byref(a), stream), "azp_nlist_fill")
-        self.max_neigh, self.n_pairs = int(stats[0]), int(stats[1])
+        self._max_neigh, self._n_pairs = int(stats[0]), int(stats[1])
+        self._stats_known = True
         # next build: rows with ~6 % head room, multiple of 8 entries (32-B aligned rows)
-        self._row_capacity = (int(self.max_neigh * 1.06) + 4 + 7) // 8 * 8
+        self._row_capacity = (int(self._max_neigh * 1.06) + 4 + 7) // 8 * 8
+        self._head_list, self._nlist, self._size = head, nlist, size
 
-        self.n_neigh, self.head_list, self.nlist, self.size = n_neigh, head, nlist, size
-        self._pos_at_build = state.pos[:n_total].clone()
-        self._order_generation = getattr(state, "order_generation", 0)
-        self._built_consumer_version = self._consumer_version
-        self._disp, self._disp_generation = 0.0, state.position_generation
-        self.num_builds += 1
-        self._keep = (rlistsq, cell_of, cell_sorted, order, cell_start, keep)
+    def _head_cache(self, N, cap, dev):
+        import torch
+
+        key = (N, cap, str(dev))
+        if getattr(self, "_head_key", None) != key:
+            self._head_fixed = torch.arange(N, dtype=torch.int64, device=dev) * cap
+            self._head_key = key
+        return self._head_fixed

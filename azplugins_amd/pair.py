@@ -43,6 +43,8 @@ class Pair(Force):
         self.use_plan = True            # LDS-staged tile kernel when the neighbor list can be tiled
         self.use_displacement_bound = True  # let it stop rows early while particles have barely moved (exact)
         self.plan_bank_order = None     # None: bank-aware rows only for long-lived lists (below); True / False: always / never
+        self.use_fused_plan = True      # sole consumer of its list: compile the plan straight from the binned particles
+        self._plan_ids = None
         self._plan = None
         self._plan_builds = None
         self._tables = None
@@ -169,7 +171,9 @@ class Pair(Force):
         tile plan lists such pairs first. 0 = no such branch."""
         return 0.0
 
-    def _pair_args(self):
+    def _pair_args(self, for_launch=False):
+        """azp_pair_args for the current state. Outside a launch the HOOMD-format list is always
+        there (a fused list is materialized first): the struct can be handed to any entry point."""
         st = self._state
         nl = self.nlist
         a = _lib.PairArgs()
@@ -181,13 +185,27 @@ class Pair(Force):
         a.d_pos = st.pos.data_ptr()
         a.box = st.box.to_c()
         a.d_n_neigh = nl.n_neigh.data_ptr()
-        a.d_nlist = nl.nlist.data_ptr()
-        a.d_head_list = nl.head_list.data_ptr()
+        fused = getattr(nl, "_fused_active", False)
+        if fused and not (for_launch and self.use_plan and self._planned_entry is not None and self.use_fused_plan):
+            nl.leave_fused_mode()  # this launch needs the HOOMD-format list (generic kernel)
+            fused = False
+        if fused:
+            # no HOOMD-format list: the tile plan compiled from the cells is its own list (ids set
+            # by _prepare_plan; placeholders until then)
+            ids = self._plan_ids if self._plan_builds == self._plan_key() else None
+            a.d_nlist, a.d_head_list = ids if ids else (nl.n_neigh.data_ptr(), nl.n_neigh.data_ptr())
+        else:
+            if self._plan_ids is not None:
+                # the plan on hand was compiled from the cells and is its own list: recompile from the u32 list
+                self._plan_ids = None
+                self._plan_builds = None
+            a.d_nlist = nl.nlist.data_ptr()
+            a.d_head_list = nl.head_list.data_ptr()
         a.d_rcutsq = self._tables["rcutsq"].data_ptr()
         a.d_ronsq = self._tables["ronsq"].data_ptr()
         if "rinnersq" in self._tables:
             a.d_rinnersq = self._tables["rinnersq"].data_ptr()
-        a.size_nlist = nl.size
+        a.size_nlist = 0 if fused else nl.size
         a.ntypes = len(st.types)
         a.shift_mode = _SHIFT[self._mode]
         a.compute_virial = 1 if self.compute_virial else 0
@@ -230,7 +248,39 @@ class Pair(Force):
         fill in the displacement fields of ``a`` for this launch."""
         if self._plan is None:
             self._plan = _lib.PairPlan()
-        key = (id(self.nlist), self.nlist.num_builds, self.threads_per_particle)
+        key = self._plan_key()
+        nl = self.nlist
+        if self._plan_builds != key and getattr(nl, "_fused_active", False):
+            # the plan straight from the binned particles: no u32 list, no hash set, one kernel
+            first, count = a.range_first, a.range_count
+            a.range_first = a.range_count = 0
+            cap = getattr(nl, "_plan_row_capacity", 0) or 160
+            info = None
+            for _ in range(3):
+                self._plan.build_from_cells(nl.cells_args(cap), a, stream)
+                info = self._plan.info()
+                if info["valid"] or info["invalid_reason"] != 3:
+                    break
+                cap = (int(info["max_row"] * 1.06) + 4 + 7) // 8 * 8  # a row overflowed: longer rows (HOOMD's protocol)
+            a.range_first, a.range_count = first, count
+            if info["valid"]:
+                nl._plan_row_capacity = max((int(info["max_row"] * 1.06) + 4 + 7) // 8 * 8, 32)
+                nl._fused_counts_ready = True
+                self._plan_ids = (info["list_id"], info["head_id"])
+                a.d_nlist, a.d_head_list = self._plan_ids
+                self._plan_builds = key
+                self._calls_since_plan = 0
+                # row classes were cut at the positions the LIST was built from, whenever this compile runs
+                self._plan_disp0 = 0.0
+                b = nl.displacement_bound(self._state)
+                known = b is not None and self.use_displacement_bound
+                a.has_displacement_bound, a.displacement_bound = (1, b) if known else (0, 0.0)
+            else:
+                # particles not spatially sorted / a tile stages too much: the list-based path
+                nl.leave_fused_mode()
+                a.d_nlist = nl.nlist.data_ptr()
+                a.d_head_list = nl.head_list.data_ptr()
+                a.size_nlist = nl.size
         if self._plan_builds != key:
             # recompile the plan only when the neighbor list was rebuilt
             first, count = a.range_first, a.range_count
@@ -248,12 +298,15 @@ class Pair(Force):
             a.has_displacement_bound, a.displacement_bound = (1 if self.use_displacement_bound else 0), 0.0
         self._calls_since_plan = getattr(self, "_calls_since_plan", 0) + 1
 
+    def _plan_key(self):
+        return (id(self.nlist), self.nlist.num_builds, self.threads_per_particle)
+
     def _wrap_args(self, a, timestep):
         """The argument struct of this potential's entry points around the common pair args."""
         return a
 
     def _launch(self, stream, timestep):
-        a = self._pair_args()
+        a = self._pair_args(for_launch=True)
         planned = self.use_plan and self._planned_entry is not None
         if planned:
             self._prepare_plan(a, stream)

@@ -193,6 +193,8 @@ def main():
                     help="sensitivity run: after the neighbor list and plan are built, move every particle by a hashed "
                          "random vector of length <= DISPLACE * r_buff / 2 (0 = the snapshot the list was built for, as "
                          "the metric is defined; 1 = the moment before the next rebuild)")
+    ap.add_argument("--no-fused-plan", action="store_true",
+                    help="build HOOMD's u32 neighbor list and compile the tile plan from it (default: plan straight from the cell list)")
     ap.add_argument("--sort-rows", action="store_true", help="experiment: sort every neighbor row by index before planning")
     ap.add_argument("--no-displacement-bound", action="store_true",
                     help="do not tell the planned kernel how far particles moved since the list was built (it then walks "
@@ -234,6 +236,8 @@ def main():
     pot.use_plan = not args.no_plan
     pot.use_displacement_bound = not args.no_displacement_bound
     sim.operations.integrator = azp.Integrator(dt=0.005, forces=[pot])
+    if args.sort_rows or args.no_fused_plan:
+        nl.fused = False  # HOOMD-format list first, plan compiled from it
     sim.run(0)  # attaches, builds the neighbor list (and the tile plan) on the GPU, first force evaluation
     if args.sort_rows:
         row = torch.repeat_interleave(torch.arange(N, device=dev, dtype=torch.int64), nl.n_neigh.to(torch.int64))
@@ -330,6 +334,7 @@ def main():
         set_state(k)
         by_step.append(dict(step=k, displacement_bound=bounds[k], bound_over_half_buffer=bounds[k] / (0.5 * r_buff), kernel_ms=timed()))
     side = {}
+    plan_info = pot.plan_info  # of the plan the timed region ran on (the side figures below recompile it)
     if n_states > 1 and not args.no_side_figures:
         # the same K launches, switching to the next cycle step at every launch (cold positions)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -358,7 +363,11 @@ def main():
                 side["every_particle_displaced_%.1f_x_half_buffer_ms" % f] = timed()
             st.pos = keep
             st.position_generation += 1
-            # the same cycle with the bank-aware row order (what a list that lives >= 50 calls gets)
+            # the same cycle with the bank-aware row order (what a list that lives >= 50 calls gets;
+            # only the list-based plan compiler orders rows that way)
+            set_state(0)
+            nl.fused = False
+            nl.compute(st, force=True)
             pot.plan_bank_order = not bool(args.bank_order)
             pot._plan_builds = None
             alt = []
@@ -371,7 +380,7 @@ def main():
     b_alg = alg_bytes_per_particle(mean_neigh)
     achieved = b_alg * N / (kernel_ms * 1e-3) / 1e9
     launch = azp._lib.last_launch()
-    kernel_name = ("azp::pair_forces_tiled_kernel<EvalPLJ>" if (pot.plan_info or {}).get("valid")
+    kernel_name = ("azp::pair_forces_tiled_kernel<EvalPLJ>" if (plan_info or {}).get("valid")
                    else "azp::pair_forces_kernel<EvalPLJ>")
     traffic, traffic_src = measured_traffic(kernel_name, cfg["name"])
     valu, valu_src = committed_counter(kernel_name, cfg["name"], "SQ_INSTS_VALU")
@@ -406,7 +415,7 @@ def main():
             "plan_bank_order": bool(pot.plan_bank_order) if n_states > 1 else None,
             "displacement_bound_passed": bool(pot.use_displacement_bound),
             "launch": launch,
-            "tile_plan": pot.plan_info,
+            "tile_plan": plan_info,
             "parallelism": "1 GPU",
         },
         "roofline": {

@@ -207,21 +207,28 @@ typedef struct azp_pair_plan azp_pair_plan; /* opaque */
 typedef struct azp_pair_plan_info
     {
     int32_t valid;
-    int32_t invalid_reason;      /* 0 none, 2: a tile lists more than 2559 distinct neighbors (or a row is too long) */
+    int32_t invalid_reason;      /* 0 none, 2: a tile lists more than 2559 distinct neighbors (or a row is too long);
+                                    3, 4, 5: see azp_pair_plan_build_from_cells */
     uint32_t threads_per_particle;
     uint32_t tile_size;          /* particles per tile (workgroup) */
     uint32_t lds_slots;          /* staged-position capacity the kernel is instantiated for */
     uint32_t n_tiles;
     uint32_t max_stage;          /* largest staged set over all tiles */
-    uint32_t _pad;
+    uint32_t max_row;            /* azp_pair_plan_build_from_cells: longest row found */
     uint64_t total_stage;        /* sum of staged-set sizes */
     uint64_t compiled_bytes;     /* size of the compiled 16-bit list */
     uint64_t builds;
+    int32_t from_cells;          /* 1: compiled by azp_pair_plan_build_from_cells */
+    uint32_t row_capacity;       /* ... with rows of this many entries */
+    uint64_t list_id, head_id;   /* ... pass these as azp_pair_args.d_nlist / d_head_list to the *_planned
+                                    entry points (the plan is its own list; there is no u32 list) */
     } azp_pair_plan_info;
 
 int azp_pair_plan_create(azp_pair_plan** out);
 void azp_pair_plan_destroy(azp_pair_plan* plan);
 int azp_pair_plan_build(azp_pair_plan* plan, const azp_pair_args* args, void* stream);
+/* (azp_pair_plan_build_from_cells, the plan compiled straight from the cell list, is declared with the
+ * neighbor-list entry points below.) */
 /* Build option: order every row bank-aware (conflict-poor LDS gathers; default on).
  * It adds ~10 % to the build and buys ~2-3 % per force call, so it pays for lists that
  * live for more than ~50 force calls; callers that rebuild more often turn it off. */
@@ -374,6 +381,18 @@ int azp_nlist_cell_assign(const azp_nlist_args* args, void* stream);
 int azp_nlist_cell_bounds(const azp_nlist_args* args, void* stream);
 int azp_nlist_count(const azp_nlist_args* args, void* stream);
 int azp_nlist_fill(const azp_nlist_args* args, void* stream);
+
+/* The plan compiled straight from the cell list, in the pass that finds the neighbors
+ * (csrc/pair_plan_cells.hip): no HOOMD-format list is produced or read. `cells`: the binned
+ * particles as for azp_nlist_fill (d_pos, box, grid, d_rlistsq, d_cell_of, d_order,
+ * d_cell_start, exclusions; d_n_neigh receives the row lengths; row_capacity = entries a row may
+ * hold, 0 = 160; d_head_list / d_nlist / d_cell_sorted unused). `pair`: d_rcutsq, d_rinnersq,
+ * r_list_max (required: sizes the buffer shells and decides where pairs must be re-imaged),
+ * ntypes. Invalid plans (azp_pair_plan_query): invalid_reason 3 = a row exceeded row_capacity
+ * (retry with max_row), 2 = a tile stages more than 2559 particles, 4 / 5 = particles not
+ * spatially sorted -- build the u32 list and azp_pair_plan_build instead. The *_planned entry
+ * points take list_id / head_id of azp_pair_plan_query as d_nlist / d_head_list. */
+int azp_pair_plan_build_from_cells(azp_pair_plan* plan, const azp_nlist_args* cells, const azp_pair_args* pair, void* stream);
 
 /* Rebuild criterion (HOOMD NeighborList::distanceCheck restated): sets *d_flag to 1
  * when any of the n particles moved farther than sqrt(max_dist_sq) from its position

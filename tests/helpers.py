@@ -252,3 +252,56 @@ def rel_err(a, b):
     b = np.asarray(b)
     scale = np.abs(b).max()
     return np.abs(a - b).max() / (scale if scale > 0 else 1.0)
+
+
+# ---------------------------------------------------------------------------
+# binned particles (azp_nlist_args) for the plan-from-cells compiler
+# ---------------------------------------------------------------------------
+def gpu_cells(pos, box, r_list, ntypes=1, N=None, exclusions=None, row_capacity=0):
+    """Bin ``pos`` (n_total x 4, ghosts after the N locals) into cells of width >= max r_list with
+    libazp's own kernels (azp_nlist_cell_assign / _cell_bounds) and return (azp_nlist_args, keepalive).
+    ``box``: (L, tilt, periodic) as for gpu_pair_args; ``exclusions``: (n_excl, excl[N, max])."""
+    import torch
+
+    pos = np.ascontiguousarray(pos, dtype=np.float64)
+    n_total = pos.shape[0]
+    N = n_total if N is None else N
+    rl = np.broadcast_to(np.asarray(r_list, dtype=np.float64), (ntypes, ntypes))
+    a = _lib.NlistArgs()
+    a.N, a.n_total, a.ntypes = N, n_total, ntypes
+    t = dict(pos=_dev(pos), rlistsq=_dev((rl * rl).reshape(-1)))
+    a.d_pos = t["pos"].data_ptr()
+    a.box = box if isinstance(box, _lib.Box) else _lib.make_box(*box)
+    L = tuple(a.box.L)
+    periodic = tuple(a.box.periodic)
+    ncell = 1
+    for k in range(3):
+        dim = max(int(np.floor(L[k] / rl.max())), 1)
+        a.grid.dim[k] = dim
+        a.grid.width[k] = L[k] / dim
+        a.grid.lo[k] = -0.5 * L[k]
+        a.grid.periodic[k] = 1 if periodic[k] else 0
+        ncell *= dim
+    a.d_rlistsq = t["rlistsq"].data_ptr()
+    t["cell_of"] = torch.empty(n_total, dtype=torch.int32, device="cuda:0")
+    a.d_cell_of = t["cell_of"].data_ptr()
+    l = _lib.lib()
+    _lib.check(l.azp_nlist_cell_assign(C.byref(a), _stream()), "azp_nlist_cell_assign")
+    t["cell_sorted"], order = torch.sort(t["cell_of"], stable=True)
+    t["order"] = order.to(torch.int32)
+    t["cell_start"] = torch.empty(ncell + 1, dtype=torch.int32, device="cuda:0")
+    a.d_cell_sorted = t["cell_sorted"].data_ptr()
+    a.d_order = t["order"].data_ptr()
+    a.d_cell_start = t["cell_start"].data_ptr()
+    _lib.check(l.azp_nlist_cell_bounds(C.byref(a), _stream()), "azp_nlist_cell_bounds")
+    if exclusions is not None:
+        n_excl, excl = exclusions
+        t["n_excl"] = _dev(n_excl, np.uint32)
+        t["excl"] = _dev(np.ascontiguousarray(np.asarray(excl, dtype=np.uint32).T))  # [max][N]
+        a.d_n_excl = t["n_excl"].data_ptr()
+        a.d_excl = t["excl"].data_ptr()
+        a.excl_pitch = N
+    t["n_neigh"] = torch.zeros(max(N, 1), dtype=torch.int32, device="cuda:0")
+    a.d_n_neigh = t["n_neigh"].data_ptr()
+    a.row_capacity = row_capacity
+    return a, t

@@ -158,6 +158,7 @@ def test_hoomd_signature_entry_runs_at_plan_speed():
     sim = azp.Simulation(device="cuda:0", seed=1)
     sim.create_state_from_snapshot(azp.Snapshot.from_arrays(cfg["xyz"], cfg["L"]))
     nl = azp.nlist.Cell(buffer=cfg["r_buff"])
+    nl.fused = False            # HOOMD hands its own u32 list to the entry point: build one
     pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=cfg["r_cut"])
     pot.params[("A", "A")] = cfg["params"]
     sim.operations.integrator = azp.Integrator(dt=0.005, forces=[pot])

@@ -68,7 +68,10 @@ def test_c3_chains_full_size():
     f_pair = np.c_[plj.forces, plj.energies]
     f_bond = np.c_[dw.forces, dw.energies]
     g = _check_against_fixture("c3_sample.npz", f_pair, f_bond)
-    assert abs(nl.n_pairs / f_pair.shape[0] - float(g["mean_neighbors"])) < 1e-9
+    # rows compiled straight from the cells hold the exact list plus a hair (single-precision
+    # acceptance test with a 1e-5 margin on r_list^2; the force kernel's FP64 cutoff test ignores them)
+    extra = nl.n_pairs / f_pair.shape[0] - float(g["mean_neighbors"])
+    assert plj.plan_info["from_cells"] == 1 and -1e-9 < extra < 1e-4 * float(g["mean_neighbors"])
     _total_force_is_zero(f_pair, "pair")
     _total_force_is_zero(f_bond, "bond")
     # generic kernel == tile kernel, and a relaunch is bit-identical

@@ -1,0 +1,308 @@
+"""The tile plan compiled straight from the cell list (azp_pair_plan_build_from_cells,
+csrc/pair_plan_cells.hip): neighbor search (HOOMD's NeighborListGPUBinned
+role for the reference's pair potentials, src/PairPotentials.h:1-60 / hoomd PotentialPairGPU)
+and plan compile in one kernel, no HOOMD-format list.
+
+Parity bar: forces, energies and virials through a plan made from the cells == the oracle's
+on the oracle's own neighbor list (1e-11 relative, FP64), for multi-type tables, all shift
+modes, ghosts + a non-periodic axis, bonded exclusions, boxes of 2-3 cells per axis (rows
+wrap inside the tile's cell block), a ragged last tile, particles that moved after the
+build (with and without the displacement bound), sub-range launches; and the fallbacks:
+rows longer than the capacity (retry with longer rows), rows / staged sets beyond the hard
+limits and particles in random memory order (list-based path).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers as H
+from azplugins_amd import synthetic as syn
+from test_gpu_parity import PAIR_PARAMS, _params_table, assert_close
+
+pytestmark = pytest.mark.gpu
+
+PLJ = "PerturbedLennardJones"
+PLANNED = {
+    PLJ: "azp_pair_forces_planned_perturbed_lennard_jones",
+    "Hertz": "azp_pair_forces_planned_hertz",
+    "ExpandedYukawa": "azp_pair_forces_planned_expanded_yukawa",
+    "Colloid": "azp_pair_forces_planned_colloid",
+}
+
+
+def fused_forces(name, pos, box, params, r_cut, r_buff, ntypes=1, N=None, mode="none", r_on=0.0, virial=False, exclusions=None,
+                 row_capacity=0, moved=None, bound=None, prange=None, r_inner=None):
+    """Bin, compile the plan from the bins, run the planned kernel; returns (force[, virial], info)."""
+    import torch
+
+    from azplugins_amd import _lib
+
+    rc = np.broadcast_to(np.asarray(r_cut, dtype=np.float64), (ntypes, ntypes))
+    rl = np.where(rc > 0, rc + r_buff, 0.0)
+    cells, keep = H.gpu_cells(pos, box, rl, ntypes, N, exclusions, row_capacity)
+    n_total = pos.shape[0]
+    N = n_total if N is None else N
+    dummy = (np.zeros(N, np.uint32), np.zeros(N, np.uint64), np.zeros(1, np.uint32))
+    a, t = H.gpu_pair_args(pos, box, dummy, ntypes, r_cut, r_on, mode, virial, N=N, r_list_max=float(rc.max() + 2 * r_buff))
+    a.d_n_neigh = keep["n_neigh"].data_ptr()
+    if r_inner is not None:
+        t["rinnersq"] = H._dev(np.full(ntypes * ntypes, float(r_inner) ** 2))
+        a.d_rinnersq = t["rinnersq"].data_ptr()
+    plan = _lib.PairPlan()
+    plan.build_from_cells(cells, a, H._stream())
+    info = plan.info()
+    if not info["valid"]:
+        return None, info
+    a.d_nlist, a.d_head_list, a.size_nlist = info["list_id"], info["head_id"], 0
+    if moved is not None:
+        t["pos"].copy_(torch.from_numpy(np.ascontiguousarray(moved)).to("cuda:0"))
+    if bound is not None:
+        a.has_displacement_bound, a.displacement_bound = 1, float(bound)
+    if prange is not None:
+        a.range_first, a.range_count = prange
+    p = H._dev(np.atleast_2d(params).astype(np.float64))
+    _lib.check(getattr(_lib.lib(), PLANNED[name])(plan.handle, C.byref(a), p.data_ptr(), H._stream()), PLANNED[name])
+    info["n_neigh"] = keep["n_neigh"].cpu().numpy()
+    return H._finish(t, virial), info
+
+
+@pytest.mark.parametrize("mode", ["none", "shift", "xplor"])
+@pytest.mark.parametrize("T", [1, 3])
+@pytest.mark.parametrize("name", [PLJ, "Hertz", "ExpandedYukawa", "Colloid"])
+def test_fused_plan_parity(oracle, name, T, mode):
+    """18^3 sites = 22.8 tiles (ragged last tile), per-type-pair cutoffs, virials."""
+    a_lat = 1.1 if name != "Colloid" else 1.6
+    pos, L, typeid = H.lattice_config(18, a_lat, 0.1 * a_lat, seed=11, ntypes=T)
+    box = oracle.make_box(L)
+    r_cut = np.full((T, T), 2.5 if name != "Colloid" else 3.2)
+    if T > 1:
+        r_cut[0, 1] = r_cut[1, 0] = r_cut[0, 0] - 0.4
+        r_cut[2, 2] = r_cut[0, 0] - 0.8
+        r_cut[0, 2] = r_cut[2, 0] = 0.0   # a pair of types that does not interact at all
+    r_on = 0.8 * r_cut
+    params = _params_table(oracle, name, T)
+    r_buff = 0.3
+    rl = np.where(r_cut > 0, r_cut + r_buff, 0.0)
+    nl = oracle.build_nlist(pos, box, rl, ntypes=T)
+    f_ref, v_ref = oracle.pair_forces(name, pos, box, nl, params, r_cut, r_on, mode, ntypes=T, virial=True)
+    (f_gpu, v_gpu), info = fused_forces(name, pos, (L,), params, r_cut, r_buff, ntypes=T, mode=mode, r_on=r_on, virial=True)
+    assert info["valid"] == 1 and info["from_cells"] == 1
+    assert_close(f_gpu, f_ref)
+    assert_close(v_gpu, v_ref, what="virial")
+    # the rows are a superset of the exact list by a hair at most (single-precision test, 1e-5 margin)
+    extra = info["n_neigh"].astype(np.int64) - nl[0].astype(np.int64)
+    assert extra.min() >= 0 and extra.sum() <= 1e-3 * nl[0].sum()
+    assert info["max_row"] == info["n_neigh"].max()
+
+
+def test_fused_plan_ghosts_nonperiodic_and_ranges(oracle):
+    """Locals first, ghosts after them (index >= N), x not periodic; whole launch and
+    the interior | boundary sub-range launches a decomposed run makes."""
+    cfg = syn.config_plj_sc(12)
+    xyz, L = cfg["xyz"], cfg["L"]
+    order = np.argsort(xyz[:, 0] > 0.0, kind="stable")
+    pos = syn.pos4(xyz[order])
+    N = int((xyz[:, 0] <= 0.0).sum())
+    box_o = oracle.make_box(L, periodic=(0, 1, 1))
+    params = oracle.pack_pair_params(PLJ, cfg["params"])
+    nl = oracle.build_nlist(pos, box_o, 2.9, N=N)
+    assert nl[2].max() >= N
+    f_ref = oracle.pair_forces(PLJ, pos, box_o, nl, params, 2.5, N=N)
+    boxg = (L, (0, 0, 0), (0, 1, 1))
+    f_gpu, info = fused_forces(PLJ, pos, boxg, params, 2.5, 0.4, N=N)
+    assert info["valid"] == 1 and info["from_cells"] == 1
+    assert f_gpu.shape == (N, 4)
+    assert_close(f_gpu, f_ref)
+    first = 300
+    for rng in ((0, first), (first, N - first)):
+        f_part, _ = fused_forces(PLJ, pos, boxg, params, 2.5, 0.4, N=N, prange=rng)
+        sl = slice(rng[0], rng[0] + rng[1])
+        assert_close(f_part[sl], f_ref[sl])
+        # planned kernels round the range outwards to whole tiles of 256 (include/azp.h): rows of
+        # tiles outside it are not touched, rows they do write are right
+        lo, hi = rng[0] // 256 * 256, min(-(-(rng[0] + rng[1]) // 256) * 256, N)
+        rest = np.ones(N, bool)
+        rest[lo:hi] = False
+        assert np.isnan(f_part[rest]).all()
+        assert_close(f_part[lo:hi], f_ref[lo:hi])
+
+
+def test_fused_plan_exclusions(oracle):
+    """Bonded partners are left out of the rows (HOOMD's exclusions=('bond',))."""
+    cfg = syn.config_chains(16, 16, 8, 8)
+    n = cfg["xyz"].shape[0]
+    pos = syn.pos4(cfg["xyz"])
+    n_excl = np.zeros(n, dtype=np.uint32)
+    excl = np.zeros((n, 2), dtype=np.uint32)
+    for a_, b_ in cfg["bonds"]:
+        for me, other in ((a_, b_), (b_, a_)):
+            excl[me, n_excl[me]] = other
+            n_excl[me] += 1
+    box = oracle.make_box(cfg["L"])
+    params = oracle.pack_pair_params("Hertz", dict(epsilon=2.0))
+    nl = oracle.build_nlist(pos, box, 2.3, exclusions=(n_excl, excl))
+    nl_all = oracle.build_nlist(pos, box, 2.3)
+    assert nl_all[0].sum() > nl[0].sum()
+    f_ref = oracle.pair_forces("Hertz", pos, box, nl, params, 2.0)
+    f_gpu, info = fused_forces("Hertz", pos, (cfg["L"],), params, 2.0, 0.3, exclusions=(n_excl, excl))
+    assert info["valid"] == 1 and info["from_cells"] == 1
+    assert_close(f_gpu, f_ref)
+    assert np.array_equal(info["n_neigh"] >= nl[0], np.ones(n, bool)) and info["n_neigh"].sum() < nl_all[0].sum()
+
+
+@pytest.mark.parametrize("n_side,r_cut", [(6, 2.5), (8, 2.5), (7, 1.2), (5, 2.0)])
+def test_fused_plan_small_boxes(oracle, n_side, r_cut):
+    """2 - 3 cells per axis: every tile's cell block covers the whole periodic axis, neighbor
+    cells wrap inside the block and pairs need the per-pair minimum image."""
+    pos, L, typeid = H.lattice_config(n_side, 1.1, 0.11, seed=5, ntypes=2)
+    r_buff = 0.25
+    assert L[0] >= 2 * (r_cut + r_buff)
+    box = oracle.make_box(L)
+    tab = H.sym_table(2, PAIR_PARAMS[PLJ])
+    params = np.array([oracle.pack_pair_params(PLJ, tab[i][j]) for i in range(2) for j in range(2)])
+    nl = oracle.build_nlist(pos, box, r_cut + r_buff, ntypes=2)
+    f_ref = oracle.pair_forces(PLJ, pos, box, nl, params, r_cut, 0.0, "shift", ntypes=2)
+    f_gpu, info = fused_forces(PLJ, pos, (L,), params, r_cut, r_buff, ntypes=2, mode="shift")
+    assert info["valid"] == 1 and info["from_cells"] == 1
+    assert_close(f_gpu, f_ref)
+    assert info["n_neigh"].sum() >= nl[0].sum()
+
+
+@pytest.mark.parametrize("frac", [0.0, 0.3, 0.99])
+def test_fused_plan_after_particles_moved(oracle, frac):
+    """Plan compiled at the build positions, kernel run after every particle moved by up to
+    frac * r_buff / 2 (some through the periodic boundary): with the bound and without it."""
+    cfg = syn.config_plj_sc(20)
+    n = cfg["xyz"].shape[0]
+    L = cfg["L"]
+    cfg["xyz"] = syn.wrap(cfg["xyz"] + np.array([0.42 * 0.8 ** (-1.0 / 3.0), 0.0, 0.0]), L)
+    pos0 = syn.pos4(cfg["xyz"])
+    box = oracle.make_box(L)
+    r_cut, r_buff = 3.0, 0.4
+    params = oracle.pack_pair_params(PLJ, cfg["params"])
+    nl = oracle.build_nlist(pos0, box, r_cut + r_buff)
+    tag = np.arange(n, dtype=np.uint64)
+    v = np.stack([syn.normal(77, tag, c) for c in range(3)], axis=1)
+    v *= (frac * 0.25 * r_buff * syn.u01(78, tag, 0) / np.linalg.norm(v, axis=1))[:, None]
+    v[:, 0] += frac * 0.25 * r_buff
+    amp = np.linalg.norm(v, axis=1).max()
+    assert amp <= 0.5 * r_buff
+    moved = syn.pos4(syn.wrap(cfg["xyz"] + v, L))
+    f_ref = oracle.pair_forces(PLJ, moved, box, nl, params, r_cut, 0.0, "shift", nthreads=8)
+    r_wca = 2.0 ** (1.0 / 6.0) * cfg["params"]["sigma"]
+    for bound in (None, amp * (1 + 1e-12)):
+        f_gpu, info = fused_forces(PLJ, pos0, (L,), params, r_cut, r_buff, mode="shift", moved=moved, bound=bound, r_inner=r_wca + r_buff)
+        assert info["valid"] == 1
+        assert_close(f_gpu, f_ref)
+
+
+def test_fused_plan_row_capacity_protocol(oracle):
+    """A row longer than the capacity invalidates the plan with reason 3 and reports the
+    longest row; the caller retries with longer rows (HOOMD's protocol for its own list)."""
+    cfg = syn.config_plj_sc(16)
+    pos = syn.pos4(cfg["xyz"])
+    L = cfg["L"]
+    params = oracle.pack_pair_params(PLJ, cfg["params"])
+    out, info = fused_forces(PLJ, pos, (L,), params, 3.0, 0.4, row_capacity=64)
+    assert out is None and info["valid"] == 0 and info["invalid_reason"] == 3 and info["from_cells"] == 1
+    box = oracle.make_box(L)
+    nl = oracle.build_nlist(pos, box, 3.4)
+    assert info["max_row"] >= nl[0].max() > 64
+    cap = (info["max_row"] + 7) // 8 * 8
+    f_gpu, info = fused_forces(PLJ, pos, (L,), params, 3.0, 0.4, row_capacity=cap)
+    assert info["valid"] == 1 and info["row_capacity"] == cap
+    assert_close(f_gpu, oracle.pair_forces(PLJ, pos, box, nl, params, 3.0))
+
+
+def test_fused_plan_limits_fall_back(oracle):
+    """Unsorted particles (a tile's cells are all over the box) and rows beyond the hard
+    limit are reported, never mis-computed; through the API the list-based path takes over
+    and the forces still match the oracle."""
+    import azplugins_amd as azp
+
+    cfg = syn.config_plj_sc(20)
+    n = cfg["xyz"].shape[0]
+    L = cfg["L"]
+    perm = np.argsort(syn.hash64(5, np.arange(n, dtype=np.uint64), 0), kind="stable")
+    xyz = cfg["xyz"][perm]
+    pos = syn.pos4(xyz)
+    params = oracle.pack_pair_params(PLJ, cfg["params"])
+    out, info = fused_forces(PLJ, pos, (L,), params, 2.5, 0.4)
+    assert out is None and info["valid"] == 0 and info["invalid_reason"] in (2, 4, 5)
+
+    box = oracle.make_box(L)
+    for r_cut, r_buff, reason in ((2.5, 0.4, (4, 5)), (5.1, 0.3, (2, 3))):
+        x = xyz if reason == (4, 5) else cfg["xyz"]
+        sim = azp.Simulation(device="cuda:0", seed=1)
+        sim.create_state_from_snapshot(azp.Snapshot.from_arrays(x, L))
+        nl = azp.nlist.Cell(buffer=r_buff)
+        pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=r_cut)
+        pot.params[("A", "A")] = cfg["params"]
+        sim.operations.integrator = azp.Integrator(dt=0.001, forces=[pot])
+        sim.operations.tuners.clear()   # no particle sorter: the memory order stays random
+        sim.run(0)
+        assert not nl._fused_active and nl._nlist is not None
+        onl = oracle.build_nlist(syn.pos4(x), box, r_cut + r_buff)
+        f_ref = oracle.pair_forces(PLJ, syn.pos4(x), box, onl, params, r_cut, nthreads=8)
+        assert_close(np.c_[pot.forces, pot.energies], f_ref)
+        assert nl.n_pairs == int(onl[0].sum())
+
+
+def test_fused_plan_through_the_api(oracle):
+    """hoomd.azplugins-shaped run: the sole consumer of a Cell list gets its plan from the
+    cells at every rebuild (no u32 list is ever filled), forces during an NVE run match the
+    oracle at the current positions, list statistics and the HOOMD-format arrays appear on
+    demand, switching the tile path off materializes the list."""
+    import azplugins_amd as azp
+
+    cfg = syn.config_plj_sc(20)
+    L = cfg["L"]
+    box = oracle.make_box(L)
+    params = oracle.pack_pair_params(PLJ, cfg["params"])
+    sim = azp.Simulation(device="cuda:0", seed=1)
+    sim.create_state_from_snapshot(azp.Snapshot.from_arrays(cfg["xyz"], L))
+    nl = azp.nlist.Cell(buffer=0.4)
+    pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=3.0, mode="shift")
+    pot.params[("A", "A")] = cfg["params"]
+    sim.operations.integrator = azp.Integrator(dt=0.005, forces=[pot], methods=[azp.ConstantVolume()])
+    sim.run(0)
+    sim.thermalize_particle_momenta(1.0, seed=3)
+    assert nl._fused_active and nl._nlist is None
+    assert pot.plan_info["valid"] == 1 and pot.plan_info["from_cells"] == 1
+    builds = nl.num_builds
+    checked = 0
+    for step in range(30):
+        sim.run(1)
+        if step % 7 == 0 or nl.num_builds != builds:
+            builds = nl.num_builds
+            pos = syn.pos4(sim.state.pos[: sim.state.N, :3].cpu().numpy())
+            onl = oracle.build_nlist(pos, box, 3.0)
+            f_ref = oracle.pair_forces(PLJ, pos, box, onl, params, 3.0, 0.0, "shift", nthreads=8)
+            assert_close(np.c_[pot.forces, pot.energies], f_ref)
+            checked += 1
+    assert nl.num_builds >= 3 and checked >= 5
+    assert nl._nlist is None                      # 30 steps, several rebuilds, no u32 list
+    assert pot.plan_info["from_cells"] == 1
+    # mode change in the middle of a list's life: the plan is recompiled from the bins of the build
+    pot.mode = "none"
+    pot.compute(0)
+    pos = syn.pos4(sim.state.pos[: sim.state.N, :3].cpu().numpy())
+    onl = oracle.build_nlist(pos, box, 3.0)
+    assert_close(np.c_[pot.forces, pot.energies], oracle.pair_forces(PLJ, pos, box, onl, params, 3.0, nthreads=8))
+    # statistics and arrays on demand
+    n_pairs = nl.n_pairs
+    assert nl._nlist is None and n_pairs > 0
+    listed = int(nl.n_neigh.sum().item())
+    head, rows = nl.head_list, nl.nlist           # materializes the HOOMD-format list for this build
+    assert nl._nlist is not None and rows.numel() >= nl.n_pairs
+    assert 0 <= listed - nl.n_pairs <= 1e-3 * listed
+    f_tile = pot.force_tensor.clone()
+    pot.use_plan = False                          # generic kernel on the u32 list
+    pot.compute(0)
+    assert_close(pot.force_tensor.cpu().numpy(), f_tile.cpu().numpy())
+    pot.use_plan = True
+    sim.run(10)
+    pos = syn.pos4(sim.state.pos[: sim.state.N, :3].cpu().numpy())
+    onl = oracle.build_nlist(pos, box, 3.0)
+    assert_close(np.c_[pot.forces, pot.energies], oracle.pair_forces(PLJ, pos, box, onl, params, 3.0, nthreads=8))

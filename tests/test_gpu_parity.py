@@ -572,6 +572,7 @@ def test_product_nlist_matches_oracle(oracle):
     sim = azp.Simulation(device="cuda:0", seed=1)
     sim.create_state_from_snapshot(snap)
     nl = azp.nlist.Cell(buffer=0.3)
+    nl.fused = False   # this test is about the HOOMD-format list (the fused path keeps none: test_gpu_fused_plan.py)
     pot = azp.pair.Hertz(nlist=nl, default_r_cut=2.0)
     pot.r_cut[("A", "B")] = 1.5
     pot.r_cut[("B", "B")] = 2.4
@@ -652,6 +653,7 @@ def test_nlist_single_pass_rebuild_and_overflow(oracle):
     sim = azp.Simulation(device="cuda:0", seed=1)
     sim.create_state_from_snapshot(azp.Snapshot.from_arrays(cfg["xyz"], cfg["L"]))
     nl = azp.nlist.Cell(buffer=0.4)
+    nl.fused = False   # the HOOMD-format list and its rebuild protocol
     pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=2.0)
     pot.params[("A", "A")] = cfg["params"]
     sim.operations.integrator = azp.Integrator(dt=0.001, forces=[pot])

@@ -26,6 +26,7 @@ ap.add_argument("--ncell", type=int, default=64)
 ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--bank", type=int, default=-1, help="-1: the library's own policy, 0 / 1: bank-aware rows off / on")
 ap.add_argument("--melt", type=int, default=0, help="NVE steps before the recorded cycle (0 = start from the lattice)")
+ap.add_argument("--fused", type=int, default=1, help="1: plan compiled straight from the cell list (default), 0: from the u32 list")
 ap.add_argument("--only", type=int, default=-1, help="time only this step of the cycle (for PMC passes)")
 args = ap.parse_args()
 
@@ -35,6 +36,7 @@ sim = azp.Simulation(device="cuda:0", seed=1)
 sim.create_state_from_snapshot(azp.Snapshot.from_arrays(cfg["xyz"], cfg["L"]))
 st = sim.state
 nl = azp.nlist.Cell(buffer=cfg["r_buff"])
+nl.fused = bool(args.fused)
 pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=cfg["r_cut"])
 pot.params[("A", "A")] = cfg["params"]
 sim.operations.integrator = azp.Integrator(dt=args.dt, forces=[pot], methods=[azp.ConstantVolume()])

@@ -10,6 +10,7 @@ cfg = syn.config_north_star(64)
 sim = azp.Simulation(device="cuda:0", seed=1)
 sim.create_state_from_snapshot(azp.Snapshot.from_arrays(cfg["xyz"], cfg["L"]))
 nl = azp.nlist.Cell(buffer=0.4)
+nl.fused = False  # these tools time the list-based plan compiler
 pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=3.0)
 pot.params[("A", "A")] = cfg["params"]
 sim.operations.integrator = azp.Integrator(dt=0.005, forces=[pot])
