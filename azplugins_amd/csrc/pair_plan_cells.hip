@@ -16,8 +16,8 @@
 //      relative to the tile's reference particle); every thread walks the runs of its member
 //      through the batch, one candidate per step. An accepted candidate is appended to the
 //      member's raw row (candidate number | class, 2 B, global scratch laid out [entry][member]
-//      so that the 64 lanes of a wave write and later read one cache line), counted under its
-//      class (per-thread counters in LDS) and marked in a bitmap;
+//      so that the 64 lanes of a wave write and later read one cache line); a second walk over
+//      the finished row counts its classes and marks its candidates in a bitmap;
 //   3. the bitmap, compacted (prefix of popcounts), gives every used candidate its LDS slot
 //      of the force kernel; the stage list is written;
 //   4. every thread turns its raw row into the force kernel's compiled row: entries ordered
@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
     uint16_t* raw_tile = a.raw + (uint64_t)tile * 256u * a.row_cap;
     const uint32_t trow = mytype * a.ntypes;
     const uint32_t nex = (a.n_excl && member) ? a.n_excl[i] : 0u;
-    if (a.stop_after == 1u)
+    if ((a.stop_after & 255u) == 1u)
         return;
 
     // ---- phase 2: stage a batch of candidates; every thread walks its member's runs through it ----
@@ -446,20 +446,38 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
         __syncthreads();
         if (member)
             {
+            // cursor: run q of my cell clipped to the batch is [g, l1); it does not depend on the tests, so
+            // the candidate of the next step is fetched from LDS before the current one is tested
             uint32_t q = 0, g = 0, l1 = 0;
-            for (;;)
+            while (g >= l1 && q < PC_RUNS)
                 {
+                const uint32_t packed = s_runs[imc_mine][q++];
+                g = max(packed & 0xffffu, b0);
+                l1 = min(packed >> 16, b0 + nbat);
+                }
+            bool have = g < l1;
+            float4 cv = cand[have ? g - b0 : 0u];
+            uint32_t ctv = (!SINGLE) ? (uint32_t)ctype[have ? g - b0 : 0u] : 0u;
+            while (have)
+                {
+                const uint32_t gc = g;
+                const float4 cc = cv;
+                const uint32_t ctc = ctv;
+                ++g;
                 while (g >= l1 && q < PC_RUNS)
                     {
                     const uint32_t packed = s_runs[imc_mine][q++];
                     g = max(packed & 0xffffu, b0);
                     l1 = min(packed >> 16, b0 + nbat);
                     }
-                if (g >= l1)
-                    break;
-                const uint32_t c = g - b0;
-                const float4 cv = cand[c];
-                float dx = xi - cv.x, dy = yi - cv.y, dz = zi - cv.z;
+                have = g < l1;
+                if (have)
+                    {
+                    cv = cand[g - b0];
+                    if (!SINGLE)
+                        ctv = ctype[g - b0];
+                    }
+                float dx = xi - cc.x, dy = yi - cc.y, dz = zi - cc.z;
                 if (wide)
                     {
                     dz = __builtin_fmaf(-bLz, rintf(dz * bLzi), dz);
@@ -471,12 +489,12 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
                 float rl = rl1;
                 if (!SINGLE)
                     {
-                    tp = trow + ctype[c];
+                    tp = trow + ctc;
                     rl = rc_cached ? s_rlistsq[tp] : (a.rlistsq[tp] > 0.0 ? (float)a.rlistsq[tp] * 1.00001f : -1.f);
                     }
                 if (rsq <= rl) // rl < 0: the type pair is not listed
                     {
-                    const uint32_t j = (uint32_t)__float_as_int(cv.w);
+                    const uint32_t j = (uint32_t)__float_as_int(cc.w);
                     bool acc = j != i;
                     for (uint32_t e = 0; e < nex; ++e)
                         acc = acc && (a.excl[(uint64_t)e * a.excl_pitch + i] != j);
@@ -492,19 +510,39 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
                             const float rcw = rc_cached ? s_rcw[tp] : sqrtf(fmaxf((float)a.rcutsq[tp], 0.f)) * shell_winv;
                             cls = pair_class(rsq, rcsq_m, rin, rcw, rscale, fmax_shell);
                             }
-                        if (cnt < a.row_cap)
-                            raw_tile[cnt * 256u + tid] = (uint16_t)((g << cbits) | cls);
+                        if (cnt < a.row_cap && !(a.stop_after & 0x100u))
+                            raw_tile[cnt * 256u + tid] = (uint16_t)((gc << cbits) | cls);
                         ++cnt;
-                        ++s_cur[cls * PC_THREADS + tid];
-                        atomicOr(&s_used[g >> 5], 1u << (g & 31u));
                         }
                     }
-                ++g;
                 }
             }
         }
+    // every thread walks its raw row once: entries per class (the cursors of phase 4 start from these
+    // totals) and the bitmap of the candidates somebody listed. Here and not in the loop above: all
+    // lanes are busy, there only the accepting sixth was
     __syncthreads();
-    if (a.stop_after == 2u)
+    if (member && !(a.stop_after & 0x200u))
+        {
+        const uint32_t nk = min(cnt, a.row_cap);
+        for (uint32_t k0 = 0; k0 < nk; k0 += 8u)
+            {
+            uint32_t e[8]; // eight loads in flight: the walk is latency-bound otherwise
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; ++u)
+                e[u] = (k0 + u < nk) ? (uint32_t)raw_tile[(k0 + u) * 256u + tid] : 0xffffffffu;
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; ++u)
+                if (e[u] != 0xffffffffu)
+                    {
+                    ++s_cur[(e[u] & cmask) * PC_THREADS + tid];
+                    const uint32_t g = e[u] >> cbits;
+                    atomicOr(&s_used[g >> 5], 1u << (g & 31u));
+                    }
+            }
+        }
+    __syncthreads();
+    if ((a.stop_after & 255u) == 2u)
         return;
     // ---- phase 3: row lengths; slot numbers = rank among the marked candidates; stage list ----
     if (member)
@@ -598,7 +636,7 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
             atomicMax(&s_kend[wave][c - 1u], (before + 7u) / 8u); // [0]: through "near", [1 + s]: through shell s
         }
     __syncthreads();
-    if (a.stop_after == 4u)
+    if ((a.stop_after & 255u) == 4u)
         return;
     // ---- phase 4: raw rows -> compiled rows (class by class, 16-byte chunks in the force kernel's lane order) ----
     const uint32_t Kcap = a.row_cap / 8u;
@@ -607,14 +645,24 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
     unsigned char* out = reinterpret_cast<unsigned char*>(a.cnl + (uint64_t)slice * Kcap * 64ull) + lane * 16u;
     for (uint32_t c = n >> 3; c < K; ++c) // the tail of the row up to the slice's rectangle: dummy slots
         *reinterpret_cast<uint4*>(out + c * 1024u) = make_uint4(0, 0, 0, 0);
-    for (uint32_t k = 0; k < n; ++k)
+    for (uint32_t k0 = 0; k0 < n; k0 += 8u)
         {
-        const uint32_t e = raw_tile[k * 256u + tid];
-        const uint32_t cls = e & cmask;
-        const uint32_t off = ((uint32_t)s_slot[e >> cbits] + 1u) * 8u;
-        const uint32_t posn = s_cur[cls * PC_THREADS + tid];
-        s_cur[cls * PC_THREADS + tid] = (uint16_t)(posn + 1u);
-        *reinterpret_cast<uint16_t*>(out + (posn >> 3) * 1024u + (posn & 7u) * 2u) = (uint16_t)off;
+        uint32_t e[8], off[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u)
+            e[u] = (k0 + u < n) ? (uint32_t)raw_tile[(k0 + u) * 256u + tid] : 0xffffffffu;
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u)
+            off[u] = (e[u] != 0xffffffffu) ? ((uint32_t)s_slot[e[u] >> cbits] + 1u) * 8u : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u)
+            if (e[u] != 0xffffffffu)
+                {
+                const uint32_t cls = e[u] & cmask;
+                const uint32_t posn = s_cur[cls * PC_THREADS + tid];
+                s_cur[cls * PC_THREADS + tid] = (uint16_t)(posn + 1u);
+                *reinterpret_cast<uint16_t*>(out + (posn >> 3) * 1024u + (posn & 7u) * 2u) = (uint16_t)off[u];
+                }
         }
     if (lane == 0)
         {
