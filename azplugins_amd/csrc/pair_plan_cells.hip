@@ -146,14 +146,18 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
     // One region, reused. Phase 0: hash sets + unsorted cells. Phase 2: the candidates of the
     // current batch (x, y, z, particle index; 16 B) + their types. Phases 3, 4: candidate -> slot.
     // The per-thread class counters / cursors live behind it through phases 2 .. 4.
-    constexpr uint32_t CAND_BYTES = PC_BATCH * 16 + PC_BATCH; // 17,408
+    constexpr uint32_t CSTRIDE = PC_BATCH + 2;                  // one pad entry: candidates are read two at a time
+    constexpr uint32_t CAND_BYTES = CSTRIDE * 16 + PC_BATCH + 32; // x | y | z | particle index | types
     constexpr uint32_t CUR_OFF = CAND_BYTES;
     constexpr uint32_t REGION = CUR_OFF + PLAN_CLASSES * PC_THREADS * 2; // + 5,120 = 22,528
     static_assert(CAND_BYTES >= 2 * PC_MAXCAND, "slot table does not fit");
     static_assert(CAND_BYTES >= (PC_SETA + PC_SETB + PC_MAXCELLS) * 4, "hash sets do not fit");
     __shared__ __attribute__((aligned(16))) unsigned char s_region[REGION];
-    float4* cand = reinterpret_cast<float4*>(s_region);
-    unsigned char* ctype = s_region + PC_BATCH * 16;
+    float* cx = reinterpret_cast<float*>(s_region);
+    float* cy = cx + CSTRIDE;
+    float* cz = cy + CSTRIDE;
+    uint32_t* cj = reinterpret_cast<uint32_t*>(cz + CSTRIDE);
+    unsigned char* ctype = s_region + CSTRIDE * 16;
     uint32_t* setA = reinterpret_cast<uint32_t*>(s_region);
     uint32_t* setB = setA + PC_SETA;
     uint32_t* s_tmp = setB + PC_SETB;
@@ -439,15 +443,18 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
             if (a.box.px) x = __builtin_fma(-a.box.Lx, rint(x * a.box.Lxinv), x);
             if (a.box.py) y = __builtin_fma(-a.box.Ly, rint(y * a.box.Lyinv), y);
             if (a.box.pz) z = __builtin_fma(-a.box.Lz, rint(z * a.box.Lzinv), z);
-            cand[t] = make_float4((float)x, (float)y, (float)z, __int_as_float((int)j));
+            cx[t] = (float)x; cy[t] = (float)y; cz[t] = (float)z;
+            cj[t] = j;
             if (!SINGLE)
                 ctype[t] = (unsigned char)type_from_w(pj.w);
             }
         __syncthreads();
         if (member)
             {
-            // cursor: run q of my cell clipped to the batch is [g, l1); it does not depend on the tests, so
-            // the candidate of the next step is fetched from LDS before the current one is tested
+            // cursor: run q of my cell clipped to the batch is [g, l1). Two candidates per step (packed
+            // single-precision math: one instruction per pair of differences / products)
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 xi2 = {xi, xi}, yi2 = {yi, yi}, zi2 = {zi, zi};
             uint32_t q = 0, g = 0, l1 = 0;
             while (g >= l1 && q < PC_RUNS)
                 {
@@ -455,63 +462,75 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
                 g = max(packed & 0xffffu, b0);
                 l1 = min(packed >> 16, b0 + nbat);
                 }
-            bool have = g < l1;
-            float4 cv = cand[have ? g - b0 : 0u];
-            uint32_t ctv = (!SINGLE) ? (uint32_t)ctype[have ? g - b0 : 0u] : 0u;
-            while (have)
+            while (g < l1)
                 {
-                const uint32_t gc = g;
-                const float4 cc = cv;
-                const uint32_t ctc = ctv;
-                ++g;
+                const uint32_t gc = g, c = g - b0;
+                const bool second = gc + 1u < l1; // (else the pad entry / the next cell's first candidate: ignored)
+                const f2 X = {cx[c], cx[c + 1u]}, Y = {cy[c], cy[c + 1u]}, Z = {cz[c], cz[c + 1u]};
+                uint32_t tpa = 0, tpb = 0;
+                float rla = rl1, rlb = rl1;
+                if (!SINGLE)
+                    {
+                    tpa = trow + ctype[c];
+                    tpb = trow + ctype[c + 1u];
+                    rla = rc_cached ? s_rlistsq[tpa] : (a.rlistsq[tpa] > 0.0 ? (float)a.rlistsq[tpa] * 1.00001f : -1.f);
+                    rlb = rc_cached ? s_rlistsq[tpb] : (a.rlistsq[tpb] > 0.0 ? (float)a.rlistsq[tpb] * 1.00001f : -1.f);
+                    }
+                g += 2u;
                 while (g >= l1 && q < PC_RUNS)
                     {
                     const uint32_t packed = s_runs[imc_mine][q++];
                     g = max(packed & 0xffffu, b0);
                     l1 = min(packed >> 16, b0 + nbat);
                     }
-                have = g < l1;
-                if (have)
-                    {
-                    cv = cand[g - b0];
-                    if (!SINGLE)
-                        ctv = ctype[g - b0];
-                    }
-                float dx = xi - cc.x, dy = yi - cc.y, dz = zi - cc.z;
+                f2 dx = xi2 - X, dy = yi2 - Y, dz = zi2 - Z;
                 if (wide)
                     {
-                    dz = __builtin_fmaf(-bLz, rintf(dz * bLzi), dz);
-                    dy = __builtin_fmaf(-bLy, rintf(dy * bLyi), dy);
-                    dx = __builtin_fmaf(-bLx, rintf(dx * bLxi), dx);
+                    const f2 kz = {rintf(dz.x * bLzi), rintf(dz.y * bLzi)}, ky = {rintf(dy.x * bLyi), rintf(dy.y * bLyi)};
+                    const f2 kx = {rintf(dx.x * bLxi), rintf(dx.y * bLxi)};
+                    dz = dz - kz * bLz;
+                    dy = dy - ky * bLy;
+                    dx = dx - kx * bLx;
                     }
-                const float rsq = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                uint32_t tp = 0;
-                float rl = rl1;
-                if (!SINGLE)
+                const f2 rsq = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                bool acca = rsq.x <= rla, accb = second && rsq.y <= rlb; // rl < 0: the type pair is not listed
+                if (acca || accb)
                     {
-                    tp = trow + ctc;
-                    rl = rc_cached ? s_rlistsq[tp] : (a.rlistsq[tp] > 0.0 ? (float)a.rlistsq[tp] * 1.00001f : -1.f);
-                    }
-                if (rsq <= rl) // rl < 0: the type pair is not listed
-                    {
-                    const uint32_t j = (uint32_t)__float_as_int(cc.w);
-                    bool acc = j != i;
+                    const uint32_t ja = cj[c], jb = cj[c + 1u];
+                    acca = acca && ja != i;
+                    accb = accb && jb != i;
                     for (uint32_t e = 0; e < nex; ++e)
-                        acc = acc && (a.excl[(uint64_t)e * a.excl_pitch + i] != j);
-                    if (acc)
                         {
-                        uint32_t cls;
-                        if (SINGLE)
-                            cls = s_ctab[min((uint32_t)(rsq * tscale), PC_CTAB - 1u)];
-                        else
-                            {
-                            const float rcsq_m = rc_cached ? s_rcutsq[tp] : (float)a.rcutsq[tp] * 1.0001f;
-                            const float rin = rc_cached ? s_rinnersq[tp] : (a.rinnersq ? (float)a.rinnersq[tp] : 0.f);
-                            const float rcw = rc_cached ? s_rcw[tp] : sqrtf(fmaxf((float)a.rcutsq[tp], 0.f)) * shell_winv;
-                            cls = pair_class(rsq, rcsq_m, rin, rcw, rscale, fmax_shell);
-                            }
+                        const uint32_t x = a.excl[(uint64_t)e * a.excl_pitch + i];
+                        acca = acca && x != ja;
+                        accb = accb && x != jb;
+                        }
+                    uint32_t clsa, clsb;
+                    if (SINGLE)
+                        {
+                        const f2 bin = rsq * tscale;
+                        clsa = s_ctab[min((uint32_t)bin.x, PC_CTAB - 1u)];
+                        clsb = s_ctab[min((uint32_t)bin.y, PC_CTAB - 1u)];
+                        }
+                    else
+                        {
+                        clsa = pair_class(rsq.x, rc_cached ? s_rcutsq[tpa] : (float)a.rcutsq[tpa] * 1.0001f,
+                                          rc_cached ? s_rinnersq[tpa] : (a.rinnersq ? (float)a.rinnersq[tpa] : 0.f),
+                                          rc_cached ? s_rcw[tpa] : sqrtf(fmaxf((float)a.rcutsq[tpa], 0.f)) * shell_winv, rscale, fmax_shell);
+                        clsb = pair_class(rsq.y, rc_cached ? s_rcutsq[tpb] : (float)a.rcutsq[tpb] * 1.0001f,
+                                          rc_cached ? s_rinnersq[tpb] : (a.rinnersq ? (float)a.rinnersq[tpb] : 0.f),
+                                          rc_cached ? s_rcw[tpb] : sqrtf(fmaxf((float)a.rcutsq[tpb], 0.f)) * shell_winv, rscale, fmax_shell);
+                        }
+                    if (acca)
+                        {
                         if (cnt < a.row_cap && !(a.stop_after & 0x100u))
-                            raw_tile[cnt * 256u + tid] = (uint16_t)((gc << cbits) | cls);
+                            raw_tile[cnt * 256u + tid] = (uint16_t)((gc << cbits) | clsa);
+                        ++cnt;
+                        }
+                    if (accb)
+                        {
+                        if (cnt < a.row_cap && !(a.stop_after & 0x100u))
+                            raw_tile[cnt * 256u + tid] = (uint16_t)(((gc + 1u) << cbits) | clsb);
                         ++cnt;
                         }
                     }
