@@ -306,3 +306,29 @@ def test_fused_plan_through_the_api(oracle):
     pos = syn.pos4(sim.state.pos[: sim.state.N, :3].cpu().numpy())
     onl = oracle.build_nlist(pos, box, 3.0)
     assert_close(np.c_[pot.forces, pot.energies], oracle.pair_forces(PLJ, pos, box, onl, params, 3.0, nthreads=8))
+
+
+def test_two_consumers_share_a_real_list(oracle):
+    """Two pair potentials on one neighbor list: the list is built in HOOMD's format (the
+    plan-from-cells shortcut is for a list with a single tile-kernel consumer), both get their
+    plans from it, each force matches the oracle with its own cutoff."""
+    import azplugins_amd as azp
+
+    pos, L, typeid = H.lattice_config(14, 1.1, 0.11, seed=3, ntypes=1)
+    box = oracle.make_box(L)
+    sim = azp.Simulation(device="cuda:0", seed=1)
+    sim.create_state_from_snapshot(azp.Snapshot.from_arrays(pos[:, :3], L))
+    nl = azp.nlist.Cell(buffer=0.3)
+    plj = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=2.5, mode="shift")
+    plj.params[("A", "A")] = PAIR_PARAMS[PLJ](0, 0)
+    hz = azp.pair.Hertz(nlist=nl, default_r_cut=1.4)
+    hz.params[("A", "A")] = dict(epsilon=3.0)
+    sim.operations.integrator = azp.Integrator(dt=0.001, forces=[plj, hz])
+    sim.run(0)
+    assert not nl._fused_active and nl._nlist is not None
+    assert plj.plan_info["from_cells"] == 0 and hz.plan_info["from_cells"] == 0
+    onl = oracle.build_nlist(pos, box, 2.8)
+    f1 = oracle.pair_forces(PLJ, pos, box, onl, oracle.pack_pair_params(PLJ, PAIR_PARAMS[PLJ](0, 0)), 2.5, 0.0, "shift")
+    f2 = oracle.pair_forces("Hertz", pos, box, onl, oracle.pack_pair_params("Hertz", dict(epsilon=3.0)), 1.4)
+    assert_close(np.c_[plj.forces, plj.energies], f1)
+    assert_close(np.c_[hz.forces, hz.energies], f2)
