@@ -31,9 +31,9 @@
  *   - outputs are OVERWRITTEN for all N local particles.
  *   - all pointers prefixed d_ are device pointers borrowed for the call. The
  *     bond, DPD, aniso, barrier, NVE, neighbor-list and generic pair kernels
- *     allocate nothing and never synchronise the stream; azp_pair_plan_build and
- *     the plan cache behind azp_pair_forces_* (see there) own device workspace
- *     and synchronise.
+ *     allocate nothing and never synchronise the stream; azp_pair_plan_build,
+ *     azp_pair_plan_build_from_cells and the plan cache behind azp_pair_forces_*
+ *     (see there) own device workspace and synchronise.
  *   - every function returns 0 on success, a positive hipError_t value if the
  *     launch failed, or a negative azp_status for invalid arguments; nothing
  *     throws across this boundary.
@@ -389,9 +389,15 @@ int azp_nlist_fill(const azp_nlist_args* args, void* stream);
  * hold, 0 = 160; d_head_list / d_nlist / d_cell_sorted unused). `pair`: d_rcutsq, d_rinnersq,
  * r_list_max (required: sizes the buffer shells and decides where pairs must be re-imaged),
  * ntypes. Invalid plans (azp_pair_plan_query): invalid_reason 3 = a row exceeded row_capacity
- * (retry with max_row), 2 = a tile stages more than 2559 particles, 4 / 5 = particles not
- * spatially sorted -- build the u32 list and azp_pair_plan_build instead. The *_planned entry
- * points take list_id / head_id of azp_pair_plan_query as d_nlist / d_head_list. */
+ * (retry with max_row; hard limit 504), 2 = a tile stages more than 2559 particles, 4 / 5 =
+ * particles not spatially sorted (the members of a tile of 256 sit in more than 128 cells, or
+ * the cells around them number more than 512 / hold more than 8192 particles), 6 = tilted box
+ * or more than 255 types -- build the u32 list and azp_pair_plan_build instead. The rows hold
+ * the exact list plus, rarely, pairs up to 5e-6 r_list beyond it (single-precision acceptance
+ * test with a margin); the force kernels' FP64 cutoff test ignores them. Synchronises the
+ * stream once; owns device workspace (2 x row_capacity x 2 B per particle + the stage lists).
+ * The *_planned entry points take list_id / head_id of azp_pair_plan_query as d_nlist /
+ * d_head_list. */
 int azp_pair_plan_build_from_cells(azp_pair_plan* plan, const azp_nlist_args* cells, const azp_pair_args* pair, void* stream);
 
 /* Rebuild criterion (HOOMD NeighborList::distanceCheck restated): sets *d_flag to 1
