@@ -28,7 +28,8 @@
 // No hash set of particles, no sort, no u32 rows, no host scan (slices have a fixed chunk
 // capacity), no cross-lane compaction anywhere (each lane owns its row), one synchronisation
 // (flags). The accepted set is a SUPERSET of the exact list by a hair (single-precision test
-// with a 1e-5 margin on r_list^2): extra entries are buffer entries the force kernel's exact
+// with a 1e-5 margin on r_list^2 plus a bound on the rounding of the staged coordinates, see rl_extra):
+// extra entries are buffer entries the force kernel's exact
 // FP64 cutoff test ignores. Classes are conservative exactly as in pair_plan.hip.
 //
 // Limits (the plan is marked invalid and the caller falls back to the list-based path): the
@@ -173,7 +174,7 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
     __shared__ unsigned char s_ctab[SINGLE ? PC_CTAB : 4];
     __shared__ uint32_t s_kend[4][PLAN_SHELLS + 1], s_smax[4];
     __shared__ float s_rcutsq[64], s_rinnersq[64], s_rcw[64], s_rlistsq[64];
-    __shared__ uint32_t s_wide, s_bad, s_ncells, s_nmc;
+    __shared__ uint32_t s_wide, s_bad, s_ncells, s_nmc, s_cmax;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t tile = blockIdx.x;
@@ -212,6 +213,7 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
         s_bad = 0;
         s_ncells = 0;
         s_nmc = 0;
+        s_cmax = 0;
         }
     for (uint32_t t = tid; t < PC_MAXCAND / 32; t += PC_THREADS)
         s_used[t] = 0;
@@ -243,6 +245,7 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
             || (a.box.py && fabs(y) + a.r_list_max >= 0.5 * a.box.Ly) || (a.box.pz && fabs(z) + a.r_list_max >= 0.5 * a.box.Lz))
             s_wide = 1;
         xi = (float)x; yi = (float)y; zi = (float)z;
+        atomicMax(&s_cmax, (uint32_t)__float_as_int(fmaxf(fabsf(xi), fmaxf(fabsf(yi), fabsf(zi))))); // (positive floats order as integers)
         mytype = (uint32_t)type_from_w(p.w);
         mycell = a.cell_of[i];
         if (set_insert(setA, PC_SETA, mycell) == 1u)
@@ -349,7 +352,12 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
     const uint32_t cbits = (NC <= 4096u) ? 4u : 3u;
     const uint32_t cmask = (1u << cbits) - 1u;
     const float fmax_shell = (cbits == 4u) ? (float)(PLAN_SHELLS - 1u) : 5.f;
-    const float rl1 = SINGLE ? (a.rlistsq[0] > 0.0 ? (float)a.rlistsq[0] * 1.00001f : -1.f) : 0.f;
+    // Acceptance test in single precision: r^2 <= r_list^2 (1 + 1e-5) + e, where e bounds what rounding the
+    // staged coordinates (|coordinate| <= cmax: the members' extent + two cells) to FP32 can do to r^2:
+    // 2 sqrt(3) r cmax 2^-23 = 4.2e-7 r cmax; taken as 1e-6 r_list cmax. A superset of the exact list, never less.
+    const float cmax = __int_as_float((int)s_cmax) + 2.f * (float)a.r_list_max;
+    const float rl_extra = 1e-6f * (float)a.r_list_max * cmax;
+    const float rl1 = SINGLE ? (a.rlistsq[0] > 0.0 ? (float)a.rlistsq[0] * 1.00001f + rl_extra : -1.f) : 0.f;
     // the runs of a member cell: its 3 x 3 rows of cells along x; a row is one or two runs of consecutive
     // cells, consecutive in the sorted cell array too (every one of them is in the set): one contiguous
     // candidate range per run
@@ -475,6 +483,8 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
                     tpb = trow + ctype[c + 1u];
                     rla = rc_cached ? s_rlistsq[tpa] : (a.rlistsq[tpa] > 0.0 ? (float)a.rlistsq[tpa] * 1.00001f : -1.f);
                     rlb = rc_cached ? s_rlistsq[tpb] : (a.rlistsq[tpb] > 0.0 ? (float)a.rlistsq[tpb] * 1.00001f : -1.f);
+                    rla = rla > 0.f ? rla + rl_extra : rla;
+                    rlb = rlb > 0.f ? rlb + rl_extra : rlb;
                     }
                 g += 2u;
                 while (g >= l1 && q < PC_RUNS)

@@ -393,8 +393,8 @@ int azp_nlist_fill(const azp_nlist_args* args, void* stream);
  * particles not spatially sorted (the members of a tile of 256 sit in more than 128 cells, or
  * the cells around them number more than 512 / hold more than 8192 particles), 6 = tilted box
  * or more than 255 types -- build the u32 list and azp_pair_plan_build instead. The rows hold
- * the exact list plus, rarely, pairs up to 5e-6 r_list beyond it (single-precision acceptance
- * test with a margin); the force kernels' FP64 cutoff test ignores them. Synchronises the
+ * the exact list plus, rarely, pairs a few 1e-6 r_list beyond it (single-precision acceptance
+ * test with a margin that covers its own rounding); the force kernels' FP64 cutoff test ignores them. Synchronises the
  * stream once; owns device workspace (2 x row_capacity x 2 B per particle + the stage lists).
  * The *_planned entry points take list_id / head_id of azp_pair_plan_query as d_nlist /
  * d_head_list. */
