@@ -305,6 +305,18 @@ def check(rc, what="libazp call"):
         raise AzpError("%s failed: status %d (%s)" % (what, rc, msg))
 
 
+def raw_stream(device):
+    """The current HIP stream of ``device`` as an integer handle (what the C ABI takes);
+    torch.cuda.current_stream(device).cuda_stream without the Stream object (4 us per launch)."""
+    import torch
+
+    try:
+        idx = device.index if isinstance(device, torch.device) else torch.device(device).index
+        return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx)
+    except AttributeError:  # private hook missing in this torch build
+        return torch.cuda.current_stream(device).cuda_stream
+
+
 def make_box(L, tilt=(0.0, 0.0, 0.0), periodic=(1, 1, 1)):
     b = Box()
     try:

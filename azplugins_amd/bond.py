@@ -90,7 +90,7 @@ class Bond(Force):
         a.compute_virial = 1 if self.compute_virial else 0
         a.block_size = self.block_size
         self._flags.zero_()
-        stream = torch.cuda.current_stream(st.device).cuda_stream
+        stream = _lib.raw_stream(st.device)
         fn = getattr(_lib.lib(), self._entry)
         _lib.check(fn(C.byref(a), self._tables["params"].data_ptr(), self._flags.data_ptr(), stream), self._entry)
         if int(self._flags.item()) != 0:

@@ -64,7 +64,7 @@ class HarmonicBarrier(Force):
         a.box = box
         a.d_params = self._tables.data_ptr()
         a.location = loc
-        stream = torch.cuda.current_stream(st.device).cuda_stream
+        stream = _lib.raw_stream(st.device)
         _lib.check(getattr(lib, self._entry)(C.byref(a), stream), self._entry)
 
 

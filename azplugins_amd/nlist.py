@@ -151,7 +151,7 @@ class Cell(NeighborList):
             self._flag = torch.zeros(2, dtype=torch.int64, device=state.pos.device)  # [flag, max |dx|^2 bits]
         self._flag.zero_()
         box = state.box.to_c()
-        stream = torch.cuda.current_stream(state.device).cuda_stream
+        stream = _lib.raw_stream(state.device)
         _lib.check(_lib.lib().azp_nlist_distance_check(state.n_max, state.pos.data_ptr(), self._pos_at_build.data_ptr(),
                                                        C.byref(box), (0.5 * self.buffer) ** 2, self._flag.data_ptr(),
                                                        self._flag.data_ptr() + 8, stream),

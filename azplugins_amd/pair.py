@@ -237,7 +237,7 @@ class Pair(Force):
         self._ensure_buffers()  # after the list: a rebuild of a decomposed run migrates particles
         if self._tables is None:
             self._build_tables()
-        stream = torch.cuda.current_stream(st.device).cuda_stream
+        stream = _lib.raw_stream(st.device)
         self._range = particle_range
         self._launch(stream, timestep)
         self._range = None

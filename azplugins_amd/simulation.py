@@ -166,7 +166,7 @@ class Simulation:
         a.box = st.box.to_c()
         a.dt = integ.dt
         lib = _lib.lib()
-        stream = torch.cuda.current_stream(st.device).cuda_stream
+        stream = _lib.raw_stream(st.device)
 
         rot = None
         if integ.integrate_rotational_dof:

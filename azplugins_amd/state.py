@@ -48,7 +48,11 @@ class Box:
         return self.xy != 0.0 or self.xz != 0.0 or self.yz != 0.0
 
     def to_c(self):
-        return _lib.make_box((self.Lx, self.Ly, self.Lz), (self.xy, self.xz, self.yz), [int(p) for p in self.periodic])
+        key = (self.Lx, self.Ly, self.Lz, self.xy, self.xz, self.yz, self.periodic)
+        if getattr(self, "_c_key", None) != key:  # (called for every launch: build the struct once per box)
+            self._c = _lib.make_box(key[:3], key[3:6], [int(p) for p in self.periodic])
+            self._c_key = key
+        return self._c
 
     def __repr__(self):
         return "Box(Lx=%g, Ly=%g, Lz=%g, xy=%g, xz=%g, yz=%g)" % (self.Lx, self.Ly, self.Lz, self.xy, self.xz, self.yz)
