@@ -149,6 +149,8 @@ class PlanInfo(C.Structure):
         ("row_capacity", C.c_uint32),
         ("list_id", C.c_uint64),
         ("head_id", C.c_uint64),
+        ("balanced", C.c_int32),
+        ("_pad", C.c_int32),
     ]
 
 
@@ -219,6 +221,7 @@ SYMBOLS = {
     "azp_pair_plan_build": (C.c_int, [_VP, C.POINTER(PairArgs), _VP]),
     "azp_pair_plan_build_from_cells": (C.c_int, [_VP, C.POINTER(NlistArgs), C.POINTER(PairArgs), _VP]),
     "azp_pair_plan_set_bank_order": (C.c_int, [_VP, C.c_int]),
+    "azp_pair_plan_set_balance": (C.c_int, [_VP, C.c_int]),
     "azp_pair_plan_query": (C.c_int, [_VP, C.POINTER(PlanInfo)]),
     "azp_pair_auto_plan_get_stats": (None, [C.POINTER(AutoPlanStats)]),
     "azp_pair_auto_plan_clear": (None, []),
@@ -342,6 +345,9 @@ class PairPlan:
 
     def build_from_cells(self, cells, pair, stream):
         check(lib().azp_pair_plan_build_from_cells(self._h, C.byref(cells), C.byref(pair), stream), "azp_pair_plan_build_from_cells")
+
+    def set_balance(self, enabled):
+        check(lib().azp_pair_plan_set_balance(self._h, int(bool(enabled))), "azp_pair_plan_set_balance")
 
     def set_bank_order(self, enabled):
         check(lib().azp_pair_plan_set_bank_order(self._h, int(bool(enabled))), "azp_pair_plan_set_bank_order")

@@ -566,6 +566,7 @@ void plan_free(PairPlan& p)
     if (p.d_cnl) (void)hipFree(p.d_cnl);
     if (p.d_flags) (void)hipFree(p.d_flags);
     if (p.d_raw) (void)hipFree(p.d_raw);
+    if (p.d_perm) (void)hipFree(p.d_perm);
     p = PairPlan();
     }
 
@@ -735,6 +736,7 @@ int plan_build(PairPlan& p, const azp_pair_args& args, hipStream_t s)
     p.valid = false;
     p.invalid_reason = 0;
     p.from_cells = false;
+    p.balanced = false;
     p.N = args.N;
     p.n_max = args.n_max;
     p.nlist_ptr = args.d_nlist;
@@ -798,6 +800,14 @@ extern "C" int azp_pair_plan_set_bank_order(azp_pair_plan* plan, int enabled)
     return AZP_SUCCESS;
     }
 
+extern "C" int azp_pair_plan_set_balance(azp_pair_plan* plan, int enabled)
+    {
+    if (!plan)
+        return AZP_ERROR_INVALID_ARGUMENT;
+    reinterpret_cast<azp::PairPlan*>(plan)->balance = enabled != 0;
+    return AZP_SUCCESS;
+    }
+
 extern "C" int azp_pair_plan_query(const azp_pair_plan* plan, azp_pair_plan_info* info)
     {
     if (!plan || !info)
@@ -815,6 +825,7 @@ extern "C" int azp_pair_plan_query(const azp_pair_plan* plan, azp_pair_plan_info
     info->builds = p->builds;
     info->max_row = p->max_row;
     info->from_cells = p->from_cells ? 1 : 0;
+    info->balanced = p->balanced ? 1 : 0;
     info->row_capacity = p->row_cap;
     info->list_id = reinterpret_cast<uint64_t>(p->nlist_ptr);
     info->head_id = reinterpret_cast<uint64_t>(p->head_ptr);

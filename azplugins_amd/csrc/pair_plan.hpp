@@ -82,6 +82,13 @@ struct PairPlan
     uint32_t max_row = 0;           // longest row seen (> row_cap: the caller retries with longer rows)
     uint16_t* d_raw = nullptr;      // raw rows (candidate number | class), scratch of the build
     size_t cap_raw = 0;
+    // build option of plans from cells (azp_pair_plan_set_balance): the rows of a tile are handed to its
+    // lanes in the order of their in-range lengths, so that each wave gets rows of similar length
+    // (the tile kernels run max-over-lanes heavy blocks per wave); d_perm[tile * 256 + lane] = member
+    bool balance = false;
+    bool balanced = false;          // this build is
+    uint8_t* d_perm = nullptr;
+    size_t cap_perm = 0;
     bool bank_order = true;         // build option (azp_pair_plan_set_bank_order)
     uint32_t stage_stride_hint = 0; // stage_idx entries to reserve per tile next time (last max + 25 %)
     // host copy of d_tile_nstage: a launch over a sub-range of tiles (domain-decomposed

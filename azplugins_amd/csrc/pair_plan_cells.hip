@@ -79,6 +79,7 @@ struct PlanCellsKArgs
     uint64_t* slice_head;
     uint4* cnl;
     uint32_t* flags;        // [1] invalid, [2] max staged set, [3] shell width, [5] longest row, [6] reason
+    uint8_t* perm;          // balanced plans: lane -> member of the tile (n_tiles x 256); NULL: lane = member
     double r_list_max;
     BoxDev box;
     int dim[3], periodic[3];
@@ -584,14 +585,30 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
             s_bad = 1;
             }
         }
+    // the lane of the force kernel that gets my row: my own, or -- balanced plans -- my rank when the
+    // members of the tile are ordered by the number of their in-range entries (longest first), so that
+    // every wave of the force kernel gets rows of similar in-range length
+    uint32_t pos_in_tile = tid;
+    if (a.perm)
+        {
+        uint32_t* s_key = &s_runs[0][0]; // (the run table is not needed any more)
+        const uint32_t nin = member ? min((uint32_t)s_cur[tid] + (uint32_t)s_cur[PC_THREADS + tid], 1023u) : 0u;
+        const uint32_t key = ((1023u - nin) << 8) | tid;
+        s_key[tid] = key;
+        __syncthreads();
+        uint32_t rank = 0;
+        for (uint32_t u = 0; u < PC_THREADS; ++u)
+            rank += (s_key[u] < key) ? 1u : 0u;
+        pos_in_tile = rank;
+        a.perm[(uint64_t)tile * 256u + rank] = (uint8_t)tid;
+        }
+    const uint32_t pw = pos_in_tile >> 6, pl = pos_in_tile & 63u; // the force kernel's wave (slice) and lane
+    atomicMax(&s_smax[pw], member ? cnt : 0u);
     uint32_t longest = member ? cnt : 0u;
     for (int off = 32; off > 0; off >>= 1)
         longest = max(longest, (uint32_t)__shfl_xor((int)longest, off, 64));
     if (lane == 0)
-        {
-        s_smax[wave] = longest; // the four waves are the force kernel's four slices
         atomicMax(&a.flags[5], longest);
-        }
     if (tid < 64)
         {
         // exclusive scan of the popcounts of the bitmap words, four per lane
@@ -662,16 +679,15 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
         s_cur[c * PC_THREADS + tid] = (uint16_t)before;
         before += v;
         if (c >= 1u && member)
-            atomicMax(&s_kend[wave][c - 1u], (before + 7u) / 8u); // [0]: through "near", [1 + s]: through shell s
+            atomicMax(&s_kend[pw][c - 1u], (before + 7u) / 8u); // [0]: through "near", [1 + s]: through shell s
         }
     __syncthreads();
     if ((a.stop_after & 255u) == 4u)
         return;
     // ---- phase 4: raw rows -> compiled rows (class by class, 16-byte chunks in the force kernel's lane order) ----
     const uint32_t Kcap = a.row_cap / 8u;
-    const uint32_t slice = tile * 4u + wave;
-    const uint32_t K = (s_smax[wave] + 7u) / 8u;
-    unsigned char* out = reinterpret_cast<unsigned char*>(a.cnl + (uint64_t)slice * Kcap * 64ull) + lane * 16u;
+    const uint32_t K = (s_smax[pw] + 7u) / 8u;
+    unsigned char* out = reinterpret_cast<unsigned char*>(a.cnl + (uint64_t)(tile * 4u + pw) * Kcap * 64ull) + pl * 16u;
     for (uint32_t c = n >> 3; c < K; ++c) // the tail of the row up to the slice's rectangle: dummy slots
         *reinterpret_cast<uint4*>(out + c * 1024u) = make_uint4(0, 0, 0, 0);
     for (uint32_t k0 = 0; k0 < n; k0 += 8u)
@@ -695,7 +711,8 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
         }
     if (lane == 0)
         {
-        a.slice_K[slice] = K;
+        const uint32_t slice = tile * 4u + wave;
+        a.slice_K[slice] = (s_smax[wave] + 7u) / 8u;
         a.slice_head[slice] = (uint64_t)slice * Kcap;
         for (uint32_t sh = 0; sh <= PLAN_SHELLS; ++sh)
             a.slice_Kend[(PLAN_SHELLS + 1) * slice + sh] = s_kend[wave][sh];
@@ -759,6 +776,9 @@ int plan_build_from_cells(PairPlan& p, const azp_nlist_args& c, const azp_pair_a
     p.total_chunks = (uint64_t)p.n_slices * (row_cap / 8u);
     AZP_HIP_TRY(ensure_buf(p.d_cnl, p.cap_cnl, (size_t)p.total_chunks * 64));
     AZP_HIP_TRY(ensure_buf(p.d_raw, p.cap_raw, (size_t)p.n_tiles * 256u * row_cap));
+    p.balanced = false;
+    if (p.balance)
+        AZP_HIP_TRY(ensure_buf(p.d_perm, p.cap_perm, (size_t)p.n_tiles * 256u));
 
     PlanCellsKArgs k;
     k.pos = c.d_pos;
@@ -780,6 +800,7 @@ int plan_build_from_cells(PairPlan& p, const azp_nlist_args& c, const azp_pair_a
     k.slice_head = p.d_slice_head;
     k.cnl = p.d_cnl;
     k.flags = p.d_flags;
+    k.perm = p.balance ? p.d_perm : nullptr;
     k.r_list_max = pa.r_list_max;
     k.box = make_box_dev(c.box);
     for (int q = 0; q < 3; ++q)
@@ -842,6 +863,7 @@ int plan_build_from_cells(PairPlan& p, const azp_nlist_args& c, const azp_pair_a
     // identity of "the list" for the planned entry points: the plan's own raw rows and slice heads
     p.nlist_ptr = reinterpret_cast<const uint32_t*>(p.d_raw);
     p.head_ptr = p.d_slice_head;
+    p.balanced = p.balance;
     p.valid = true;
     return AZP_SUCCESS;
     }

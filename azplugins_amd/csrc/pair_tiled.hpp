@@ -48,6 +48,7 @@ struct TiledKArgs
                                  // PLAN_SHELLS = whole rows
     const uint64_t* slice_head;
     const uint4* cnl;
+    const uint8_t* perm;         // balanced plans (one lane per particle): lane -> member of the tile; NULL = identity
     };
 
 // Stride (in slots) between the x, y and z arrays in LDS. With a stride of CAP the compiler
@@ -358,7 +359,7 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
     // this lane's own particle: its load is issued first and consumed after the staging
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63; // wave id: scalar
     const uint32_t pl = lane / TPP;
-    const uint32_t idx = first + wave * PW + pl;
+    const uint32_t idx = first + ((TPP == 1 && a.perm) ? (uint32_t)a.perm[(uint64_t)tile * 256u + tid] : wave * PW + pl);
     const bool active = idx < a.p.end;
     const double4 own = load_scalar4(a.p.pos, active ? idx : first);
     // All loads of the staging are issued before the first result is used: the index
@@ -535,6 +536,7 @@ int launch_tiled_instance2(const PairPlan& plan, const azp_pair_args& args, cons
     k.tile_nstage = plan.d_tile_nstage;
     k.tile_head = plan.d_tile_head;
     k.stage_idx = plan.d_stage_idx;
+    k.perm = plan.balanced ? plan.d_perm : nullptr;
     k.slice_K = plan.d_slice_K;
     k.slice_Kend = plan.d_slice_Kend;
     k.n_shells = plan_shells_for(plan, args);

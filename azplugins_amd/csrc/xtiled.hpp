@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256, X::kMinWaves) xtiled_kernel(const TiledKA
         if (!SINGLE) s_type[0] = 0;
         }
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63;
-    const uint32_t idx = first + wave * 64u + lane;
+    const uint32_t idx = first + (a.perm ? (uint32_t)a.perm[(uint64_t)tile * 256u + tid] : wave * 64u + lane);
     const bool active = idx < a.p.end;
     const bool no_hint = !(a.p.r_list_max > 0.0);
     bool lane_wide = a.p.box.triclinic;
@@ -244,6 +244,7 @@ int launch_xtiled_instance(const PairPlan& plan, const azp_pair_args& args, cons
     k.tile_nstage = plan.d_tile_nstage;
     k.tile_head = plan.d_tile_head;
     k.stage_idx = plan.d_stage_idx;
+    k.perm = plan.balanced ? plan.d_perm : nullptr;
     k.slice_K = plan.d_slice_K;
     k.slice_Kend = plan.d_slice_Kend;
     k.n_shells = plan_shells_for(plan, args);

@@ -24,6 +24,7 @@ class Pair(Force):
     _cpp_class_name = None          # name the reference registers in _azplugins
     _entry = None                   # libazp entry point
     _planned_entry = None           # tile-plan entry point (isotropic pairs)
+    _plan_balance = False           # plans from cells: rows to lanes by in-range length (expensive, ragged pair blocks)
     _schema = {}
     _param_doubles = 4              # size of the raw param struct in doubles
     _accepted_modes = ("none", "shift", "xplor")
@@ -256,6 +257,7 @@ class Pair(Force):
             a.range_first = a.range_count = 0
             cap = getattr(nl, "_plan_row_capacity", 0) or 160
             info = None
+            self._plan.set_balance(self._plan_balance)
             for _ in range(3):
                 self._plan.build_from_cells(nl.cells_args(cap), a, stream)
                 info = self._plan.info()
@@ -411,6 +413,7 @@ class DPDGeneralWeight(Pair):
     _halo_fields = ("pos", "vel")   # (ghost tags change only when the ghosts are re-selected)
     _entry = "azp_dpd_forces_general_weight"
     _planned_entry = "azp_dpd_forces_planned_general_weight"
+    _plan_balance = True
     _schema = dict(A=float, gamma=float, s=float)
     _accepted_modes = ("none",)
 
@@ -470,6 +473,7 @@ class TwoPatchMorse(Pair):
     _halo_fields = ("pos", "orientation")
     _entry = "azp_aniso_forces_two_patch_morse"
     _planned_entry = "azp_aniso_forces_planned_two_patch_morse"
+    _plan_balance = True
     _schema = dict(M_d=float, M_r=float, r_eq=float, omega=float, alpha=float, repulsion=bool)
     _param_doubles = 6
     _accepted_modes = ("none", "shift")

@@ -222,11 +222,21 @@ typedef struct azp_pair_plan_info
     uint32_t row_capacity;       /* ... with rows of this many entries */
     uint64_t list_id, head_id;   /* ... pass these as azp_pair_args.d_nlist / d_head_list to the *_planned
                                     entry points (the plan is its own list; there is no u32 list) */
+    int32_t balanced;            /* 1: rows handed to the lanes in the order of their in-range lengths
+                                    (azp_pair_plan_set_balance) */
+    int32_t _pad;
     } azp_pair_plan_info;
 
 int azp_pair_plan_create(azp_pair_plan** out);
 void azp_pair_plan_destroy(azp_pair_plan* plan);
 int azp_pair_plan_build(azp_pair_plan* plan, const azp_pair_args* args, void* stream);
+/* Build option of azp_pair_plan_build_from_cells (default off): within every tile of 256 particles the
+ * rows are handed to the force kernel's lanes longest in-range row first, so that each of its four waves
+ * gets rows of similar in-range length. The tile kernels run as many heavy per-pair blocks per wave as
+ * the LONGEST in-range row of the wave has entries; for potentials whose pair block is expensive and
+ * whose rows are short and ragged (DPD thermostat: Philox per pair, 12.6 +- 3 in range) that is the
+ * difference between max-over-256 and the quartile maxima. Results are those of the unbalanced plan. */
+int azp_pair_plan_set_balance(azp_pair_plan* plan, int enabled);
 /* (azp_pair_plan_build_from_cells, the plan compiled straight from the cell list, is declared with the
  * neighbor-list entry points below.) */
 /* Build option: order every row bank-aware (conflict-poor LDS gathers; default on).

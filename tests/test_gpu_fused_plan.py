@@ -32,7 +32,7 @@ PLANNED = {
 
 
 def fused_forces(name, pos, box, params, r_cut, r_buff, ntypes=1, N=None, mode="none", r_on=0.0, virial=False, exclusions=None,
-                 row_capacity=0, moved=None, bound=None, prange=None, r_inner=None):
+                 row_capacity=0, moved=None, bound=None, prange=None, r_inner=None, balance=False):
     """Bin, compile the plan from the bins, run the planned kernel; returns (force[, virial], info)."""
     import torch
 
@@ -50,6 +50,7 @@ def fused_forces(name, pos, box, params, r_cut, r_buff, ntypes=1, N=None, mode="
         t["rinnersq"] = H._dev(np.full(ntypes * ntypes, float(r_inner) ** 2))
         a.d_rinnersq = t["rinnersq"].data_ptr()
     plan = _lib.PairPlan()
+    plan.set_balance(balance)
     plan.build_from_cells(cells, a, H._stream())
     info = plan.info()
     if not info["valid"]:
@@ -332,3 +333,76 @@ def test_two_consumers_share_a_real_list(oracle):
     f2 = oracle.pair_forces("Hertz", pos, box, onl, oracle.pack_pair_params("Hertz", dict(epsilon=3.0)), 1.4)
     assert_close(np.c_[plj.forces, plj.energies], f1)
     assert_close(np.c_[hz.forces, hz.energies], f2)
+
+
+def test_balanced_plan_is_the_same_list(oracle):
+    """azp_pair_plan_set_balance: rows go to the force kernel's lanes longest in-range row first.
+    Same pairs, same per-particle sums up to the order of the additions inside a class; ragged
+    rows (a random fluid at low density), a ragged last tile, sub-range launches."""
+    cfg = syn.config_dpd(5000)           # uniform random positions, rho = 3: rows of 5 .. 25 in-range entries
+    pos = syn.pos4(cfg["xyz"])
+    L = cfg["L"]
+    box = oracle.make_box(L)
+    params = oracle.pack_pair_params("Hertz", dict(epsilon=2.5))
+    nl = oracle.build_nlist(pos, box, 1.4)
+    f_ref, v_ref = oracle.pair_forces("Hertz", pos, box, nl, params, 1.0, virial=True)
+    (f_plain, v_plain), info0 = fused_forces("Hertz", pos, (L,), params, 1.0, 0.4, virial=True)
+    (f_bal, v_bal), info1 = fused_forces("Hertz", pos, (L,), params, 1.0, 0.4, virial=True, balance=True)
+    assert info0["balanced"] == 0 and info1["balanced"] == 1 and info1["valid"] == 1
+    assert_close(f_plain, f_ref)
+    assert_close(f_bal, f_ref)
+    assert_close(v_bal, v_ref, what="virial")
+    n = pos.shape[0]
+    f_part, _ = fused_forces("Hertz", pos, (L,), params, 1.0, 0.4, balance=True, prange=(512, 1024))
+    assert_close(f_part[512:1536], f_ref[512:1536])
+    assert np.isnan(f_part[:512]).all() and np.isnan(f_part[1536:]).all()
+    assert n % 256 != 0
+
+
+@pytest.mark.parametrize("kind", ["dpd", "tpm"])
+def test_balanced_plans_through_the_api(oracle, kind):
+    """The DPD thermostat and TwoPatchMorse ask for balanced plans (their pair blocks are expensive,
+    their rows short and ragged): forces (and torques) against the oracle, during a short NVE run."""
+    import azplugins_amd as azp
+
+    if kind == "dpd":
+        cfg = syn.config_dpd(6000)
+        sim = azp.Simulation(device="cuda:0", seed=cfg["seed"])
+        sim.create_state_from_snapshot(azp.Snapshot.from_arrays(cfg["xyz"], cfg["L"], velocity=cfg["vel"], tag=cfg["tag"]))
+        nl = azp.nlist.Cell(buffer=cfg["r_buff"])
+        pot = azp.pair.DPDGeneralWeight(nlist=nl, kT=cfg["kT"], default_r_cut=cfg["r_cut"])
+        dt = cfg["dt"]
+    else:
+        cfg = syn.config_tpm(12, 12, 16)
+        sim = azp.Simulation(device="cuda:0", seed=1)
+        sim.create_state_from_snapshot(azp.Snapshot.from_arrays(cfg["xyz"], cfg["L"], orientation=cfg["orientation"]))
+        nl = azp.nlist.Cell(buffer=cfg["r_buff"])
+        pot = azp.pair.TwoPatchMorse(nlist=nl, default_r_cut=cfg["r_cut"], mode="shift")
+        dt = 0.002
+    pot.params[("A", "A")] = cfg["params"]
+    sim.operations.integrator = azp.Integrator(dt=dt, forces=[pot], methods=[azp.ConstantVolume()])
+    sim.operations.tuners.clear()
+    sim.run(0)
+    info = pot.plan_info
+    assert info["valid"] == 1 and info["from_cells"] == 1 and info["balanced"] == 1
+    box = oracle.make_box(cfg["L"])
+    for steps in (0, 6):
+        sim.run(steps)
+        pot.compute(sim.timestep)   # (the run's last evaluation saw the half-kicked velocities)
+        st = sim.state
+        n = st.N
+        pos = st.pos[:n].cpu().numpy()
+        onl = oracle.build_nlist(pos, box, cfg["r_cut"])
+        if kind == "dpd":
+            vel = st.vel[:n].cpu().numpy()
+            tag = st.tag[:n].cpu().numpy().view(np.uint32)
+            params = oracle.pack_pair_params("DPDGeneralWeight", cfg["params"])
+            f_ref = oracle.dpd_forces(pos, vel, tag, box, onl, params, cfg["r_cut"], kT=cfg["kT"], dt=dt, seed=cfg["seed"],
+                                      timestep=sim.timestep)
+            assert_close(np.c_[pot.forces, pot.energies], f_ref, what="dpd after %d steps" % steps)
+        else:
+            q = st.orientation[:n].cpu().numpy()
+            params = oracle.pack_pair_params("TwoPatchMorse", cfg["params"])
+            f_ref, t_ref = oracle.aniso_forces_tpm(pos, q, box, onl, params, cfg["r_cut"], "shift")
+            assert_close(np.c_[pot.forces, pot.energies], f_ref, what="tpm force after %d steps" % steps)
+            assert_close(pot.torques, t_ref[:, :3], what="tpm torque")
