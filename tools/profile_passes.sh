@@ -1,3 +1,5 @@
+# The rocprofv3 passes behind profiles/r02_*: run on a GPU box from the repository root
+# (gpurun -- bash tools/profile_passes.sh); summaries are then condensed into profiles/ by hand.
 set -e
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r02q
