@@ -46,6 +46,15 @@
 
 namespace azp
 {
+// Profiling variant (make variant SRC=pair_plan_cells NAME=pcprof DEFS=-DAZP_PLAN_CELLS_PROFILE, loaded through
+// AZP_LIB_PATH): AZP_PLAN_CELLS_STOP=p in the environment leaves the kernel after phase p (1, 2, 4; + 256: no raw-row
+// stores, + 512: no row walk) and the build reports the plan invalid (reason 7). Compiled out of libazp.so.
+#ifdef AZP_PLAN_CELLS_PROFILE
+#define PC_PROFILE_AND(x) && (x)
+#else
+#define PC_PROFILE_AND(x)
+#endif
+
 constexpr uint32_t PC_THREADS = 256;
 constexpr uint32_t PC_BATCH = 1024;     // candidates staged at a time
 constexpr uint32_t PC_MAXCAND = 8192;   // candidates of a tile's cells (13 bits of a raw entry; 12 when they suffice)
@@ -86,7 +95,7 @@ struct PlanCellsKArgs
     uint32_t N, n_total, ntypes;
     uint32_t row_cap;       // multiple of 8
     uint32_t stage_stride;
-    uint32_t stop_after;    // profiling only (AZP_PLAN_CELLS_STOP): leave after this phase, the plan is then unusable
+    uint32_t stop_after;    // AZP_PLAN_CELLS_PROFILE builds only (tools/plan_cells_probe.py): leave after this phase
     };
 
 // Distinct coordinates of the cells next to cell c along one axis, ascending: c - 1, c, c + 1
@@ -426,8 +435,10 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
     uint16_t* raw_tile = a.raw + (uint64_t)tile * 256u * a.row_cap;
     const uint32_t trow = mytype * a.ntypes;
     const uint32_t nex = (a.n_excl && member) ? a.n_excl[i] : 0u;
+#ifdef AZP_PLAN_CELLS_PROFILE
     if ((a.stop_after & 255u) == 1u)
         return;
+#endif
 
     // ---- phase 2: stage a batch of candidates; every thread walks its member's runs through it ----
     uint32_t cnt = 0;
@@ -534,13 +545,13 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
                         }
                     if (acca)
                         {
-                        if (cnt < a.row_cap && !(a.stop_after & 0x100u))
+                        if (cnt < a.row_cap PC_PROFILE_AND(!(a.stop_after & 0x100u)))
                             raw_tile[cnt * 256u + tid] = (uint16_t)((gc << cbits) | clsa);
                         ++cnt;
                         }
                     if (accb)
                         {
-                        if (cnt < a.row_cap && !(a.stop_after & 0x100u))
+                        if (cnt < a.row_cap PC_PROFILE_AND(!(a.stop_after & 0x100u)))
                             raw_tile[cnt * 256u + tid] = (uint16_t)(((gc + 1u) << cbits) | clsb);
                         ++cnt;
                         }
@@ -552,7 +563,7 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
     // totals) and the bitmap of the candidates somebody listed. Here and not in the loop above: all
     // lanes are busy, there only the accepting sixth was
     __syncthreads();
-    if (member && !(a.stop_after & 0x200u))
+    if (member PC_PROFILE_AND(!(a.stop_after & 0x200u)))
         {
         const uint32_t nk = min(cnt, a.row_cap);
         for (uint32_t k0 = 0; k0 < nk; k0 += 8u)
@@ -572,8 +583,10 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
             }
         }
     __syncthreads();
+#ifdef AZP_PLAN_CELLS_PROFILE
     if ((a.stop_after & 255u) == 2u)
         return;
+#endif
     // ---- phase 3: row lengths; slot numbers = rank among the marked candidates; stage list ----
     if (member)
         {
@@ -682,8 +695,10 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
             atomicMax(&s_kend[pw][c - 1u], (before + 7u) / 8u); // [0]: through "near", [1 + s]: through shell s
         }
     __syncthreads();
+#ifdef AZP_PLAN_CELLS_PROFILE
     if ((a.stop_after & 255u) == 4u)
         return;
+#endif
     // ---- phase 4: raw rows -> compiled rows (class by class, 16-byte chunks in the force kernel's lane order) ----
     const uint32_t Kcap = a.row_cap / 8u;
     const uint32_t K = (s_smax[pw] + 7u) / 8u;
@@ -812,7 +827,11 @@ int plan_build_from_cells(PairPlan& p, const azp_nlist_args& c, const azp_pair_a
     k.n_total = c.n_total;
     k.ntypes = c.ntypes;
     k.row_cap = row_cap;
+#ifdef AZP_PLAN_CELLS_PROFILE
     static const uint32_t stop_after = []() { const char* e = getenv("AZP_PLAN_CELLS_STOP"); return e ? (uint32_t)atoi(e) : 0u; }();
+#else
+    const uint32_t stop_after = 0;
+#endif
     k.stop_after = stop_after;
 
     uint32_t stride = p.stage_stride_hint;

@@ -1,5 +1,9 @@
 """Time of azp_pair_plan_build_from_cells (cell binning excluded) on the north-star system,
-whole and phase by phase (AZP_PLAN_CELLS_STOP=1|2|4 leaves the kernel after that phase).
+whole and phase by phase: AZP_PLAN_CELLS_STOP=1|2|4 leaves the kernel after that phase, in the profiling build of
+the library only --
+
+    make -C azplugins_amd/csrc variant SRC=pair_plan_cells NAME=pcprof DEFS=-DAZP_PLAN_CELLS_PROFILE
+    AZP_LIB_PATH=tools/libazp_pcprof.so AZP_PLAN_CELLS_STOP=2 python tools/plan_cells_probe.py
 
     python tools/plan_cells_probe.py [--ncell 64] [--reps 10] [--melt 0]
 """

@@ -12,7 +12,7 @@ rocprofv3 --kernel-trace --stats -d $O/md_stats --output-format csv -- python3 t
 tail -3 $O/md_bench.log
 python3 tools/md_bench.py --steps 300 > $O/md_bench_noprof.log 2>&1
 tail -3 $O/md_bench_noprof.log
-for s in 0 1 2 514 4; do AZP_PLAN_CELLS_STOP=$s python3 tools/plan_cells_probe.py 2>&1 | tail -1 | cut -c1-60; done > $O/plan_cells_phases.log
+for s in 0 1 2 514 4; do AZP_LIB_PATH=tools/libazp_pcprof.so AZP_PLAN_CELLS_STOP=$s python3 tools/plan_cells_probe.py 2>&1 | tail -1 | cut -c1-60; done > $O/plan_cells_phases.log
 python3 tools/plan_cells_probe.py --melt 100 2>&1 | tail -1 | cut -c1-60 >> $O/plan_cells_phases.log
 cat $O/plan_cells_phases.log
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS -d $O/pc_sq --output-format csv -- python3 tools/plan_cells_probe.py --reps 3 > $O/pc_sq.log 2> $O/pc_sq.err
