@@ -65,6 +65,7 @@ constexpr uint32_t PC_SETA = 512, PC_SETB = 1024; // hash sets: member cells, th
 constexpr uint32_t PC_ROWMAX = 512;     // largest row capacity + 8 (PLAN_ROWBUF)
 constexpr uint32_t PC_EMPTY = 0xffffffffu;
 constexpr uint32_t PC_CTAB = 1024;      // bins of the r^2 -> class table (one particle type)
+constexpr uint32_t PC_WALK = 8;         // raw-row entries a thread has in flight in the row walks (latency-bound otherwise; 16 buys nothing more)
 
 struct PlanCellsKArgs
     {
@@ -566,14 +567,14 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
     if (member PC_PROFILE_AND(!(a.stop_after & 0x200u)))
         {
         const uint32_t nk = min(cnt, a.row_cap);
-        for (uint32_t k0 = 0; k0 < nk; k0 += 8u)
+        for (uint32_t k0 = 0; k0 < nk; k0 += PC_WALK)
             {
-            uint32_t e[8]; // eight loads in flight: the walk is latency-bound otherwise
+            uint32_t e[PC_WALK];
 #pragma unroll
-            for (uint32_t u = 0; u < 8u; ++u)
+            for (uint32_t u = 0; u < PC_WALK; ++u)
                 e[u] = (k0 + u < nk) ? (uint32_t)raw_tile[(k0 + u) * 256u + tid] : 0xffffffffu;
 #pragma unroll
-            for (uint32_t u = 0; u < 8u; ++u)
+            for (uint32_t u = 0; u < PC_WALK; ++u)
                 if (e[u] != 0xffffffffu)
                     {
                     ++s_cur[(e[u] & cmask) * PC_THREADS + tid];
@@ -705,17 +706,17 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
     unsigned char* out = reinterpret_cast<unsigned char*>(a.cnl + (uint64_t)(tile * 4u + pw) * Kcap * 64ull) + pl * 16u;
     for (uint32_t c = n >> 3; c < K; ++c) // the tail of the row up to the slice's rectangle: dummy slots
         *reinterpret_cast<uint4*>(out + c * 1024u) = make_uint4(0, 0, 0, 0);
-    for (uint32_t k0 = 0; k0 < n; k0 += 8u)
+    for (uint32_t k0 = 0; k0 < n; k0 += PC_WALK)
         {
-        uint32_t e[8], off[8];
+        uint32_t e[PC_WALK], off[PC_WALK];
 #pragma unroll
-        for (uint32_t u = 0; u < 8u; ++u)
+        for (uint32_t u = 0; u < PC_WALK; ++u)
             e[u] = (k0 + u < n) ? (uint32_t)raw_tile[(k0 + u) * 256u + tid] : 0xffffffffu;
 #pragma unroll
-        for (uint32_t u = 0; u < 8u; ++u)
+        for (uint32_t u = 0; u < PC_WALK; ++u)
             off[u] = (e[u] != 0xffffffffu) ? ((uint32_t)s_slot[e[u] >> cbits] + 1u) * 8u : 0u;
 #pragma unroll
-        for (uint32_t u = 0; u < 8u; ++u)
+        for (uint32_t u = 0; u < PC_WALK; ++u)
             if (e[u] != 0xffffffffu)
                 {
                 const uint32_t cls = e[u] & cmask;
