@@ -132,3 +132,37 @@ def test_c5_two_patch_morse_full_size():
     tpm.compute(0)
     assert float((tpm.force_tensor - first_f).abs().max()) <= 1e-11 * float(first_f.abs().max())
     assert float((tpm.torque_tensor - first_t).abs().max()) <= 1e-11 * float(first_t.abs().max())
+
+
+def test_north_star_liquid_after_sort_and_rebuilds(oracle):
+    """N = 1,048,576 as an MD run leaves it: the lattice melted for 60 NVE steps at kT = 1
+    (six list rebuilds on HOOMD's criterion), the particles re-indexed by the sorter (tiles now
+    straddle the sorter's blocks), 12 more steps. The forces of the product path -- plan compiled
+    from the cell list at every rebuild, rows stopped at the displacement bound -- against the
+    oracle on its own list at the same positions, all particles."""
+    import azplugins_amd as azp
+
+    cfg = syn.config_north_star(64)
+    azp_, sim = _sim(cfg)
+    nl = azp.nlist.Cell(buffer=cfg["r_buff"])
+    pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=cfg["r_cut"], mode="shift")
+    pot.params[("A", "A")] = cfg["params"]
+    sim.operations.integrator = azp.Integrator(dt=0.005, forces=[pot], methods=[azp.ConstantVolume()])
+    sim.operations.tuners.clear()
+    sim.run(0)
+    sim.thermalize_particle_momenta(1.0, seed=11)
+    sim.run(60)
+    azp.ParticleSorter().sort(sim)
+    sim.run(12)
+    assert nl.num_builds >= 7 and pot.plan_info["valid"] == 1 and pot.plan_info["from_cells"] == 1
+    assert nl.displacement_bound(sim.state) is not None
+    n = sim.state.N
+    pos = sim.state.pos[:n].cpu().numpy()
+    box = oracle.make_box(cfg["L"])
+    onl = oracle.build_nlist(pos, box, cfg["r_cut"])
+    params = oracle.pack_pair_params("PerturbedLennardJones", cfg["params"])
+    f_ref = oracle.pair_forces("PerturbedLennardJones", pos, box, onl, params, cfg["r_cut"], 0.0, "shift", nthreads=8)
+    f = np.c_[pot.forces, pot.energies]
+    scale = np.abs(f_ref).max()
+    assert np.abs(f - f_ref).max() <= 1e-10 * scale
+    _total_force_is_zero(f, "pair")
