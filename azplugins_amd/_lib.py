@@ -222,6 +222,7 @@ SYMBOLS = {
     "azp_pair_plan_build_from_cells": (C.c_int, [_VP, C.POINTER(NlistArgs), C.POINTER(PairArgs), _VP]),
     "azp_pair_plan_set_bank_order": (C.c_int, [_VP, C.c_int]),
     "azp_pair_plan_set_balance": (C.c_int, [_VP, C.c_int]),
+    "azp_pair_plan_tile_stage": (C.c_int, [_VP, C.POINTER(C.c_uint32), C.c_uint32]),
     "azp_pair_plan_query": (C.c_int, [_VP, C.POINTER(PlanInfo)]),
     "azp_pair_auto_plan_get_stats": (None, [C.POINTER(AutoPlanStats)]),
     "azp_pair_auto_plan_clear": (None, []),
@@ -345,6 +346,15 @@ class PairPlan:
 
     def build_from_cells(self, cells, pair, stream):
         check(lib().azp_pair_plan_build_from_cells(self._h, C.byref(cells), C.byref(pair), stream), "azp_pair_plan_build_from_cells")
+
+    def tile_stage(self):
+        """Staged-set size of every tile of the last build (numpy uint32)."""
+        import numpy as np
+
+        n = self.info()["n_tiles"]
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        m = lib().azp_pair_plan_tile_stage(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32)), n)
+        return out[:max(m, 0)]
 
     def set_balance(self, enabled):
         check(lib().azp_pair_plan_set_balance(self._h, int(bool(enabled))), "azp_pair_plan_set_balance")

@@ -808,6 +808,17 @@ extern "C" int azp_pair_plan_set_balance(azp_pair_plan* plan, int enabled)
     return AZP_SUCCESS;
     }
 
+extern "C" int azp_pair_plan_tile_stage(const azp_pair_plan* plan, uint32_t* out, uint32_t n)
+    {
+    if (!plan || !out)
+        return AZP_ERROR_INVALID_ARGUMENT;
+    const azp::PairPlan* p = reinterpret_cast<const azp::PairPlan*>(plan);
+    const uint32_t m = std::min<uint32_t>(n, (uint32_t)p->h_tile_nstage.size());
+    for (uint32_t t = 0; t < m; ++t)
+        out[t] = p->h_tile_nstage[t];
+    return (int)m;
+    }
+
 extern "C" int azp_pair_plan_query(const azp_pair_plan* plan, azp_pair_plan_info* info)
     {
     if (!plan || !info)

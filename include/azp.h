@@ -237,6 +237,9 @@ int azp_pair_plan_build(azp_pair_plan* plan, const azp_pair_args* args, void* st
  * whose rows are short and ragged (DPD thermostat: Philox per pair, 12.6 +- 3 in range) that is the
  * difference between max-over-256 and the quartile maxima. Results are those of the unbalanced plan. */
 int azp_pair_plan_set_balance(azp_pair_plan* plan, int enabled);
+/* Diagnostics: the staged-set size of the first n tiles of the last build (host copy, no device access);
+ * returns the number of entries written. */
+int azp_pair_plan_tile_stage(const azp_pair_plan* plan, uint32_t* out, uint32_t n);
 /* (azp_pair_plan_build_from_cells, the plan compiled straight from the cell list, is declared with the
  * neighbor-list entry points below.) */
 /* Build option: order every row bank-aware (conflict-poor LDS gathers; default on).

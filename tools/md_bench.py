@@ -63,3 +63,11 @@ if args.sort_period:
     print("particle sorts: %d (%.1f ms of host time)" % (sim.operations.tuners[0].num_sorts, 1e3 * getattr(sim.operations.tuners[0], "host_seconds", 0.0)))
 print("force kernel on the final state: %.4f ms/launch; mean neighbors %.1f; plan %s" % (
     ev0.elapsed_time(ev1) / 100, nl.n_pairs / N, {k: pot.plan_info[k] for k in ("valid", "lds_slots", "max_stage")} if pot.use_plan else None))
+if pot.use_plan and pot._plan is not None:
+    import numpy as np
+
+    ts = pot._plan.tile_stage()
+    if ts.size:
+        q = np.percentile(ts, [0, 25, 50, 75, 90, 99, 100]).astype(int)
+        print("staged particles per tile: min %d, quartiles %d / %d / %d, 90 %% %d, 99 %% %d, max %d; tiles <= 1536: %.1f %%, <= 1664: %.1f %%" % (
+            q[0], q[1], q[2], q[3], q[4], q[5], q[6], 100.0 * (ts <= 1536).mean(), 100.0 * (ts <= 1664).mean()))
