@@ -4,6 +4,8 @@
 // src/HarmonicBarrier.h:150-177 / src/HarmonicBarrierGPU.cuh:49-84.
 // Pure streaming: 32 B in, 32 B out per particle, one lane per particle,
 // per-type (k, offset) pairs in LDS.
+#include <algorithm>
+
 #include "azp_device.hpp"
 #include "pair_kernel_host.hpp"
 
@@ -453,6 +455,45 @@ __global__ void __launch_bounds__(256) sorter_keys_kernel(uint32_t n, const doub
     double fx = p.x * box.Lxinv + 0.5, fy = p.y * box.Lyinv + 0.5, fz = p.z * box.Lzinv + 0.5;
     fx -= floor(fx); fy -= floor(fy); fz -= floor(fz);
     const uint32_t cx = min((uint32_t)(fx * dimx), dimx - 1), cy = min((uint32_t)(fy * dimy), dimy - 1), cz = min((uint32_t)(fz * dimz), dimz - 1);
+    if (block == 0)
+        {
+        // Hilbert index of the cell in the enclosing 2^b cube (Skilling, "Programming the Hilbert curve", 2004:
+        // axes -> transpose, then the bits of the three words interleaved, X[0] most significant): any run of
+        // consecutive cells is a compact blob, so 256 consecutive particles make a compact tile wherever the run starts
+        uint32_t b = 1;
+        while ((1u << b) < max(dimx, max(dimy, dimz)))
+            ++b;
+        uint32_t X[3] = {cx, cy, cz};
+        const uint32_t M = 1u << (b - 1);
+        for (uint32_t Q = M; Q > 1; Q >>= 1)
+            {
+            const uint32_t P = Q - 1;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                {
+                if (X[k] & Q)
+                    X[0] ^= P;
+                else
+                    {
+                    const uint32_t t = (X[0] ^ X[k]) & P;
+                    X[0] ^= t;
+                    X[k] ^= t;
+                    }
+                }
+            }
+        X[1] ^= X[0];
+        X[2] ^= X[1];
+        uint32_t t = 0;
+        for (uint32_t Q = M; Q > 1; Q >>= 1)
+            if (X[2] & Q)
+                t ^= Q - 1;
+        X[0] ^= t; X[1] ^= t; X[2] ^= t;
+        uint32_t h = 0;
+        for (int bit = (int)b - 1; bit >= 0; --bit)
+            h = (h << 3) | (((X[0] >> bit) & 1u) << 2) | (((X[1] >> bit) & 1u) << 1) | ((X[2] >> bit) & 1u);
+        keys[i] = (int32_t)h;
+        return;
+        }
     const uint32_t nbx = (dimx + block - 1) / block, nby = (dimy + block - 1) / block;
     const uint32_t key = ((cz / block) * nby + (cy / block)) * nbx + (cx / block);
     const uint32_t inner = ((cz % block) * block + (cy % block)) * block + (cx % block);
@@ -465,11 +506,20 @@ extern "C" int azp_sorter_keys(uint32_t n, const double* d_pos, const azp_box* b
     {
     if (n == 0)
         return AZP_SUCCESS;
-    if (!d_pos || !box || !dims || !d_keys || block == 0 || dims[0] == 0 || dims[1] == 0 || dims[2] == 0)
+    if (!d_pos || !box || !dims || !d_keys || dims[0] == 0 || dims[1] == 0 || dims[2] == 0)
         return AZP_ERROR_INVALID_ARGUMENT;
-    const uint64_t nkeys = (uint64_t)((dims[0] + block - 1) / block) * ((dims[1] + block - 1) / block) * ((dims[2] + block - 1) / block)
-                           * block * block * block;
-    if (nkeys >= (1ull << 31))
+    uint64_t nkeys;
+    if (block == 0)
+        {
+        uint32_t b = 1;
+        while ((1u << b) < std::max(dims[0], std::max(dims[1], dims[2])))
+            ++b;
+        nkeys = 1ull << (3 * b); // Hilbert index in the enclosing 2^b cube
+        }
+    else
+        nkeys = (uint64_t)((dims[0] + block - 1) / block) * ((dims[1] + block - 1) / block) * ((dims[2] + block - 1) / block) * block * block
+                * block;
+    if (nkeys > (1ull << 31))
         return AZP_ERROR_INVALID_ARGUMENT; // keys are int32 (torch's fast sort path)
     hipLaunchKernelGGL(azp::sorter_keys_kernel, dim3((n + 255u) / 256u), dim3(256), 0, static_cast<hipStream_t>(stream), n, d_pos,
                        azp::make_box_dev(*box), 0.0, dims[0], dims[1], dims[2], block, d_keys);

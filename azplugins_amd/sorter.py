@@ -13,7 +13,12 @@ from . import _lib
 
 
 class ParticleSorter:
-    def __init__(self, trigger_period=500, block=4, particles_per_block=256):
+    def __init__(self, trigger_period=500, block=4, particles_per_block=256, curve="hilbert"):
+        """``curve``: "hilbert" (cells of ~4 particles along a Hilbert curve: any 256 consecutive particles
+        form a compact blob) or "blocks" (row-major blocks of ``block``^3 cells, row-major inside)."""
+        if curve not in ("hilbert", "blocks"):
+            raise ValueError("curve must be 'hilbert' or 'blocks'")
+        self.curve = curve
         self.trigger_period = int(trigger_period)
         self.block = int(block)
         self.particles_per_block = int(particles_per_block)
@@ -35,7 +40,8 @@ class ParticleSorter:
         keys = torch.empty(N, dtype=torch.int32, device=state.device)
         box = state.box.to_c()
         stream = torch.cuda.current_stream(state.device).cuda_stream
-        _lib.check(_lib.lib().azp_sorter_keys(N, state.pos.data_ptr(), C.byref(box), dims, self.block, keys.data_ptr(), stream), "azp_sorter_keys")
+        _lib.check(_lib.lib().azp_sorter_keys(N, state.pos.data_ptr(), C.byref(box), dims, 0 if self.curve == "hilbert" else self.block,
+                                              keys.data_ptr(), stream), "azp_sorter_keys")
         return keys
 
     def sort(self, sim):

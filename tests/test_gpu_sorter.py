@@ -92,3 +92,85 @@ def test_sorter_in_run_loop_keeps_trajectory():
         if period:
             assert sim.operations.tuners[0].num_sorts == 4
     assert np.abs(out[0] - out[1]).max() < 1e-10
+
+
+def _hilbert(cx, cy, cz, b):
+    """Skilling's axes -> Hilbert index (restated in Python; checked on the CPU in test_host_cpu.py)."""
+    X = [cx, cy, cz]
+    M = 1 << (b - 1)
+    Q = M
+    while Q > 1:
+        P = Q - 1
+        for k in range(3):
+            if X[k] & Q:
+                X[0] ^= P
+            else:
+                t = (X[0] ^ X[k]) & P
+                X[0] ^= t
+                X[k] ^= t
+        Q >>= 1
+    X[1] ^= X[0]
+    X[2] ^= X[1]
+    t = 0
+    Q = M
+    while Q > 1:
+        if X[2] & Q:
+            t ^= Q - 1
+        Q >>= 1
+    X = [x ^ t for x in X]
+    h = 0
+    for bit in range(b - 1, -1, -1):
+        h = (h << 3) | (((X[0] >> bit) & 1) << 2) | (((X[1] >> bit) & 1) << 1) | ((X[2] >> bit) & 1)
+    return h
+
+
+def test_hilbert_keys_are_the_hilbert_curve():
+    """azp_sorter_keys with block = 0: the keys of the 12 x 9 x 7 cells visit every cell once, in steps of
+    one cell wherever the enclosing 16^3 curve stays inside the grid, and equal the Python restatement."""
+    import ctypes as C
+
+    import torch
+
+    from azplugins_amd import _lib
+
+    dims = (12, 9, 7)
+    L = (6.0, 4.5, 3.5)
+    cells = np.array([(x, y, z) for z in range(dims[2]) for y in range(dims[1]) for x in range(dims[0])])
+    xyz = (cells + 0.5) * 0.5 - 0.5 * np.array(L)
+    pos = torch.from_numpy(syn.pos4(xyz)).to("cuda:0")
+    keys = torch.empty(len(cells), dtype=torch.int32, device="cuda:0")
+    box = _lib.make_box(L)
+    cdims = (C.c_uint32 * 3)(*dims)
+    _lib.check(_lib.lib().azp_sorter_keys(len(cells), pos.data_ptr(), C.byref(box), cdims, 0, keys.data_ptr(), None), "azp_sorter_keys")
+    torch.cuda.synchronize()
+    got = keys.cpu().numpy()
+    want = np.array([_hilbert(int(x), int(y), int(z), 4) for x, y, z in cells])
+    assert np.array_equal(got, want) and len(set(got.tolist())) == len(cells)
+    order = cells[np.argsort(got)]
+    steps = np.abs(np.diff(order, axis=0)).sum(axis=1)
+    assert np.median(steps) == 1 and (steps == 1).mean() > 0.8   # (the curve leaves and re-enters a non-cubic grid)
+
+
+def test_sorted_liquid_tiles_are_compact():
+    """A jittered lattice in random memory order: after a Hilbert sort 256 consecutive particles form a
+    compact blob wherever the run starts -- every tile can be staged, the plan is compiled straight from the
+    cells, and the staged sets are smaller than with the row-major block order."""
+    cfg = syn.config_plj_sc(28)
+    n = cfg["xyz"].shape[0]
+    perm = np.argsort(syn.u01(43, np.arange(n, dtype=np.uint64), 0))
+    sim = azp.Simulation(device="cuda:0", seed=1)
+    sim.create_state_from_snapshot(azp.Snapshot.from_arrays(cfg["xyz"][perm], cfg["L"]))
+    nl = azp.nlist.Cell(buffer=0.4)
+    pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=3.0)
+    pot.params[("A", "A")] = cfg["params"]
+    sim.operations.integrator = azp.Integrator(dt=0.001, forces=[pot])
+    sim.operations.tuners.clear()
+    azp.ParticleSorter(curve="hilbert").sort(sim)
+    sim.run(0)
+    info = pot.plan_info
+    assert info["valid"] == 1 and info["from_cells"] == 1 and n % 256 != 0
+    hilbert_mean = pot._plan.tile_stage().mean()
+    azp.ParticleSorter(curve="blocks").sort(sim)
+    sim.run(0)
+    assert pot.plan_info["valid"] == 1
+    assert hilbert_mean < pot._plan.tile_stage().mean()

@@ -22,6 +22,7 @@ ap.add_argument("--dt", type=float, default=0.005)
 ap.add_argument("--ncell", type=int, default=64)
 ap.add_argument("--no-plan", action="store_true")
 ap.add_argument("--sort-period", type=int, default=200, help="re-index the particles every this many steps (0 = never)")
+ap.add_argument("--curve", default="hilbert", help="particle sorter: hilbert | blocks")
 args = ap.parse_args()
 
 cfg = syn.config_north_star(args.ncell)
@@ -35,7 +36,7 @@ pot.use_plan = not args.no_plan
 sim.operations.integrator = azp.Integrator(dt=args.dt, forces=[pot], methods=[azp.ConstantVolume()])
 sim.operations.tuners.clear()
 if args.sort_period:
-    sim.operations.tuners.append(azp.ParticleSorter(trigger_period=args.sort_period))
+    sim.operations.tuners.append(azp.ParticleSorter(trigger_period=args.sort_period, curve=args.curve))
 sim.run(0)
 sim.thermalize_particle_momenta(args.kT, seed=7)
 sim.run(50)  # melt the lattice a little, warm the allocator
