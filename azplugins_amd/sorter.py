@@ -1,6 +1,6 @@
 """Particle sorter ("+ particle SFC sort"): the role of
-``hoomd.update.ParticleSorter``. Reorders the local particles along a blocked
-cell curve so that 256 consecutive particles form a compact tile -- the order the
+``hoomd.update.ParticleSorter``. Reorders the local particles along a Hilbert
+curve through small cells so that any 256 consecutive particles form a compact tile -- the order the
 tile plan (``pair_plan.hpp``) and the neighbor-list build rely on. Tags, images,
 velocities, orientations travel with the particles; bonds are re-indexed.
 
