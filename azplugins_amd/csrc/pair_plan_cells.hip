@@ -93,7 +93,7 @@ struct PlanCellsKArgs
     double r_list_max;
     BoxDev box;
     int dim[3], periodic[3];
-    uint32_t N, n_total, ntypes;
+    uint32_t N, n_total, ntypes, n_tiles;
     uint32_t row_cap;       // multiple of 8
     uint32_t stage_stride;
     uint32_t stop_after;    // AZP_PLAN_CELLS_PROFILE builds only (tools/plan_cells_probe.py): leave after this phase
@@ -188,7 +188,11 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
     __shared__ uint32_t s_wide, s_bad, s_ncells, s_nmc, s_cmax;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t tile = blockIdx.x;
+    // (grid padded to a multiple of 8: each XCD compiles one contiguous eighth of the tiles, whose
+    // candidate cells overlap, out of its own L2)
+    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+    if (tile >= a.n_tiles)
+        return;
     const uint32_t first = tile * 256u;
     const uint32_t count = min(256u, a.N - first);
     const bool member = tid < count;
@@ -827,6 +831,7 @@ int plan_build_from_cells(PairPlan& p, const azp_nlist_args& c, const azp_pair_a
     k.N = c.N;
     k.n_total = c.n_total;
     k.ntypes = c.ntypes;
+    k.n_tiles = p.n_tiles;
     k.row_cap = row_cap;
 #ifdef AZP_PLAN_CELLS_PROFILE
     static const uint32_t stop_after = []() { const char* e = getenv("AZP_PLAN_CELLS_STOP"); return e ? (uint32_t)atoi(e) : 0u; }();
@@ -847,9 +852,9 @@ int plan_build_from_cells(PairPlan& p, const azp_nlist_args& c, const azp_pair_a
         k.stage_idx = p.d_stage_idx;
         k.stage_stride = stride;
         if (c.ntypes == 1)
-            hipLaunchKernelGGL(plan_cells_kernel<true>, dim3(p.n_tiles), dim3(PC_THREADS), 0, s, k);
+            hipLaunchKernelGGL(plan_cells_kernel<true>, dim3((p.n_tiles + 7u) & ~7u), dim3(PC_THREADS), 0, s, k);
         else
-            hipLaunchKernelGGL(plan_cells_kernel<false>, dim3(p.n_tiles), dim3(PC_THREADS), 0, s, k);
+            hipLaunchKernelGGL(plan_cells_kernel<false>, dim3((p.n_tiles + 7u) & ~7u), dim3(PC_THREADS), 0, s, k);
         AZP_HIP_TRY(hipGetLastError());
         AZP_HIP_TRY(hipMemcpyAsync(h_flags, p.d_flags, sizeof(h_flags), hipMemcpyDeviceToHost, s));
         p.h_tile_nstage.resize(p.n_tiles);
