@@ -406,3 +406,72 @@ def test_balanced_plans_through_the_api(oracle, kind):
             f_ref, t_ref = oracle.aniso_forces_tpm(pos, q, box, onl, params, cfg["r_cut"], "shift")
             assert_close(np.c_[pot.forces, pot.energies], f_ref, what="tpm force after %d steps" % steps)
             assert_close(pot.torques, t_ref[:, :3], what="tpm torque")
+
+
+def _random_case(seed):
+    """A random small system for the plan-from-cells compiler: box shape, periodicity, density, number
+    of types, per-pair cutoffs, buffer, N not a multiple of 256, memory order by cells."""
+    rng = np.random.RandomState(seed)
+    ntypes = int(rng.randint(1, 4))
+    r_cut_max = float(rng.uniform(1.0, 3.0))
+    r_buff = float(rng.uniform(0.1, 0.5))
+    r_list = r_cut_max + r_buff
+    cells = rng.randint(2, 7, size=3)                       # cells per axis
+    L = cells * r_list * rng.uniform(1.0, 1.3, size=3)
+    rho = float(rng.uniform(0.15, 0.9)) * min(1.0, (2.6 / r_list) ** 3 * 1.2)   # keep rows and staged sets within the limits
+    n = int(max(40, min(9000, rho * np.prod(L))))
+    periodic = tuple(int(v) for v in rng.randint(0, 2, size=3))
+    if rng.rand() < 0.5:
+        periodic = (1, 1, 1)
+    # jittered lattice positions (no overlapping pairs: the potentials stay finite), then a cell-curve memory order
+    side = int(np.ceil(n ** (1.0 / 3.0)))
+    grid = np.stack(np.meshgrid(*[np.arange(side)] * 3, indexing="ij"), axis=-1).reshape(-1, 3)[:n]
+    a = L / side
+    tag = np.arange(n, dtype=np.uint64)
+    jit = np.stack([syn.u01(seed * 7 + 1, tag, c) - 0.5 for c in range(3)], axis=1) * 0.6
+    xyz = (grid + 0.5 + jit) * a - 0.5 * L
+    xyz = np.clip(xyz, -0.5 * L * (1 - 1e-9), 0.5 * L * (1 - 1e-9))
+    dim = np.maximum((L / (0.5 * r_list)).astype(np.int64), 1)
+    c = np.minimum(((xyz + 0.5 * L) / (L / dim)).astype(np.int64), dim - 1)
+    b = 2
+    key = ((c[:, 2] // b) * ((dim[1] + b - 1) // b) + (c[:, 1] // b)) * ((dim[0] + b - 1) // b) + (c[:, 0] // b)
+    inner = ((c[:, 2] % b) * b + (c[:, 1] % b)) * b + (c[:, 0] % b)
+    order = np.lexsort((inner, key))
+    xyz = xyz[order]
+    typeid = (syn.hash64(seed + 5, tag, 3) % np.uint64(ntypes)).astype(np.int64)
+    r_cut = np.full((ntypes, ntypes), r_cut_max)
+    for i in range(ntypes):
+        for j in range(i, ntypes):
+            r_cut[i, j] = r_cut[j, i] = r_cut_max * float(rng.choice([1.0, 0.8, 0.6]))
+    r_cut[0, 0] = r_cut_max
+    min_sep = 0.4 * float(a.min())
+    return dict(pos=syn.pos4(xyz, typeid), L=L, periodic=periodic, ntypes=ntypes, r_cut=r_cut, r_buff=r_buff, min_sep=min_sep,
+                mode=str(rng.choice(["none", "shift", "xplor"])), name=str(rng.choice([PLJ, "Hertz", "ExpandedYukawa"])),
+                n_ghost=int(rng.randint(0, n // 4)) if periodic != (1, 1, 1) else 0, balance=bool(rng.randint(0, 2)))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fused_plan_random_systems(oracle, seed):
+    """Forty random systems (box shape 2-6 cells per axis, any periodicity, densities 0.15-0.9, 1-3 types with
+    per-pair cutoffs, ghosts, balanced or not): either the plan from the cells gives the oracle's forces, or it
+    is reported invalid with one of the documented reasons."""
+    cse = _random_case(seed)
+    pos, L, T = cse["pos"], cse["L"], cse["ntypes"]
+    N = pos.shape[0] - cse["n_ghost"]
+    box_o = oracle.make_box(L, periodic=cse["periodic"])
+    rl = cse["r_cut"] + cse["r_buff"]
+    nl = oracle.build_nlist(pos, box_o, rl, N=N, ntypes=T)
+    tab = H.sym_table(T, PAIR_PARAMS[cse["name"]])
+    params = np.array([oracle.pack_pair_params(cse["name"], tab[i][j]) for i in range(T) for j in range(T)])
+    r_on = 0.8 * cse["r_cut"]
+    f_ref, v_ref = oracle.pair_forces(cse["name"], pos, box_o, nl, params, cse["r_cut"], r_on, cse["mode"], N=N, ntypes=T, virial=True)
+    out, info = fused_forces(cse["name"], pos, (L, (0, 0, 0), cse["periodic"]), params, cse["r_cut"], cse["r_buff"], ntypes=T, N=N,
+                             mode=cse["mode"], r_on=r_on, virial=True, balance=cse["balance"], row_capacity=504)
+    if out is None:
+        assert info["invalid_reason"] in (2, 3, 4, 5), info
+        return
+    assert info["valid"] == 1 and info["from_cells"] == 1 and info["balanced"] == int(cse["balance"])
+    assert_close(out[0], f_ref, what="seed %d force" % seed)
+    assert_close(out[1], v_ref, what="seed %d virial" % seed)
+    extra = info["n_neigh"].astype(np.int64) - nl[0].astype(np.int64)
+    assert extra.min() >= 0 and extra.sum() <= 1e-3 * max(nl[0].sum(), 1000)
