@@ -363,3 +363,19 @@ def test_azplugins_extension_module_classes_and_dict_round_trip(oracle):
     dw = dict(r_0=1.0, r_1=2.0, U_1=1.0, U_tilt=0.5)
     w.setParams("A-A", dw)
     assert w.getParams("A-A") == dw
+
+
+def test_hilbert_restatement_is_a_hilbert_curve():
+    """The Python restatement of Skilling's axes -> Hilbert index that the GPU test compares
+    azp_sorter_keys against: a bijection on the 2^b cube whose consecutive indices are face neighbors."""
+    import itertools
+
+    from test_gpu_sorter import _hilbert
+
+    for b in (1, 2, 3, 4):
+        n = 1 << b
+        cells = list(itertools.product(range(n), repeat=3))
+        keys = [_hilbert(x, y, z, b) for x, y, z in cells]
+        assert sorted(keys) == list(range(n ** 3))
+        order = [c for _, c in sorted(zip(keys, cells))]
+        assert all(sum(abs(p - q) for p, q in zip(order[k], order[k + 1])) == 1 for k in range(len(order) - 1))
