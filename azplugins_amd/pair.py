@@ -266,6 +266,7 @@ class Pair(Force):
                 cap = (int(info["max_row"] * 1.06) + 4 + 7) // 8 * 8  # a row overflowed: longer rows (HOOMD's protocol)
             a.range_first, a.range_count = first, count
             if info["valid"]:
+                nl._fused_failures = 0
                 nl._plan_row_capacity = max((int(info["max_row"] * 1.06) + 4 + 7) // 8 * 8, 32)
                 nl._fused_counts_ready = True
                 self._plan_ids = (info["list_id"], info["head_id"])
@@ -278,7 +279,12 @@ class Pair(Force):
                 known = b is not None and self.use_displacement_bound
                 a.has_displacement_bound, a.displacement_bound = (1, b) if known else (0, 0.0)
             else:
-                # particles not spatially sorted / a tile stages too much: the list-based path
+                # particles not spatially sorted / a tile stages too much: the list-based path. A list
+                # whose tiles fail twice in a row (e.g. the thin boundary shells of a decomposed DPD
+                # fluid: 256 particles in more than 128 cells) stops trying at every rebuild
+                nl._fused_failures = getattr(nl, "_fused_failures", 0) + 1
+                if nl._fused_failures >= 2:
+                    nl.fused = False
                 nl.leave_fused_mode()
                 a.d_nlist = nl.nlist.data_ptr()
                 a.d_head_list = nl.head_list.data_ptr()
