@@ -2,7 +2,7 @@
 # (gpurun -- bash tools/profile_passes.sh); summaries are then condensed into profiles/ by hand.
 set -e
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r02q
+O=gpurun_out/r02w
 mkdir -p $O
 export TMPDIR=/tmp
 B="python3 bench.py --no-cpu-baseline --no-side-figures --steps 80 --warmup 8"
