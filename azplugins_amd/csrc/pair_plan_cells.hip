@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
     constexpr uint32_t CSTRIDE = PC_BATCH + 2;                  // one pad entry: candidates are read two at a time
     constexpr uint32_t CAND_BYTES = CSTRIDE * 16 + PC_BATCH + 32; // x | y | z | particle index | types
     constexpr uint32_t CUR_OFF = CAND_BYTES;
-    constexpr uint32_t REGION = CUR_OFF + PLAN_CLASSES * PC_THREADS * 2; // + 5,120 = 22,528
+    constexpr uint32_t REGION = CUR_OFF + PLAN_CLASSES * PC_THREADS * 2; // + 5,120 = 22,592
     static_assert(CAND_BYTES >= 2 * PC_MAXCAND, "slot table does not fit");
     static_assert(CAND_BYTES >= (PC_SETA + PC_SETB + PC_MAXCELLS) * 4, "hash sets do not fit");
     __shared__ __attribute__((aligned(16))) unsigned char s_region[REGION];

@@ -75,5 +75,8 @@ pc += ["", "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them, uncorrecte
        "build). SQ_INSTS_VALU x 4 cycles / 1,024 SIMDs = %.2f M cycles of VALU issue per build: the kernel is bound by VALU issue" % (vals.get("SQ_INSTS_VALU", 0) * 4 / 1024 / 1e6),
        "(candidate tests: 850 per particle, two per step with packed FP32 math) at the ~1.6-1.8 GHz the chip holds under this load.",
        "SQ_LDS_IDX_ACTIVE / 256 CUs = %.2f M cycles: the per-lane LDS reads of the staged candidates are the co-limit." % (vals.get("SQ_LDS_IDX_ACTIVE", 0) / 256 / 1e6)]
+pc += ["", "Experiments on the final kernel that changed nothing (same box, 1.37-1.41 ms): three workgroups per CU instead of four",
+       "(4 KiB of padding in LDS), candidates as 16-byte records read with `ds_read_b128` instead of three `ds_read2_b32`, 16 raw",
+       "entries in flight in the row walks instead of 8, XCD-aware tile order. 2,048 candidates per batch (two workgroups per CU): 1.72 ms."]
 open(os.path.join(P, "r02_plan_cells.md"), "w").write("\n".join(pc) + "\n")
 print("\n".join(pc))
