@@ -59,7 +59,7 @@ constexpr uint32_t PC_THREADS = 256;
 constexpr uint32_t PC_BATCH = 1024;     // candidates staged at a time
 constexpr uint32_t PC_MAXCAND = 8192;   // candidates of a tile's cells (13 bits of a raw entry; 12 when they suffice)
 constexpr uint32_t PC_MAXCELLS = 512;   // distinct cells next to a tile's members
-constexpr uint32_t PC_MAXMC = 128;      // distinct cells of the members themselves
+constexpr uint32_t PC_MAXMC = 128;      // distinct cells of the members themselves (more LDS here costs a workgroup per CU: 1.40 -> 1.66 ms)
 constexpr uint32_t PC_RUNS = 18;        // 3 x 3 rows of cells, each at most two runs
 constexpr uint32_t PC_SETA = 512, PC_SETB = 1024; // hash sets: member cells, their neighbor cells
 constexpr uint32_t PC_ROWMAX = 512;     // largest row capacity + 8 (PLAN_ROWBUF)
