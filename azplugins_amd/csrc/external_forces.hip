@@ -457,13 +457,17 @@ __global__ void __launch_bounds__(256) sorter_keys_kernel(uint32_t n, const doub
     const uint32_t cx = min((uint32_t)(fx * dimx), dimx - 1), cy = min((uint32_t)(fy * dimy), dimy - 1), cz = min((uint32_t)(fz * dimz), dimz - 1);
     if (block == 0)
         {
-        // Hilbert index of the cell in the enclosing 2^b cube (Skilling, "Programming the Hilbert curve", 2004:
-        // axes -> transpose, then the bits of the three words interleaved, X[0] most significant): any run of
-        // consecutive cells is a compact blob, so 256 consecutive particles make a compact tile wherever the run starts
+        // Hilbert index (Skilling, "Programming the Hilbert curve", 2004: axes -> transpose, then the bits of the
+        // three words interleaved, X[0] most significant) on a 2^b x 2^b x 2^b grid stretched over the whole box,
+        // 2^b >= the largest of dims: the curve never leaves the box, so any run of consecutive cells is a compact
+        // blob and 256 consecutive particles make a compact tile wherever the run starts. (On a dims grid that is
+        // not a power of two the curve of the enclosing cube leaves and re-enters, and the tiles across such a gap
+        // come in two distant pieces.)
         uint32_t b = 1;
         while ((1u << b) < max(dimx, max(dimy, dimz)))
             ++b;
-        uint32_t X[3] = {cx, cy, cz};
+        const uint32_t side = 1u << b;
+        uint32_t X[3] = {min((uint32_t)(fx * side), side - 1), min((uint32_t)(fy * side), side - 1), min((uint32_t)(fz * side), side - 1)};
         const uint32_t M = 1u << (b - 1);
         for (uint32_t Q = M; Q > 1; Q >>= 1)
             {

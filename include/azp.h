@@ -426,8 +426,8 @@ int azp_nlist_distance_check(uint32_t n, const double* d_pos, const double* d_po
 /* Sort keys of the particle sorter (the role of HOOMD's SFC sorter, which the tile plan relies
  * on): key of particle i = index of its cell along a blocked curve over a dims[0] x dims[1] x
  * dims[2] grid (block^3 cells per block, blocks and the cells inside them in row-major order), or,
- * with block = 0, its index along the Hilbert curve through the enclosing 2^b cube (<= 1024 cells per
- * axis); positions wrapped into the orthorhombic frame of `box`. */
+ * with block = 0, the index along the Hilbert curve of a 2^b x 2^b x 2^b grid stretched over the box
+ * (2^b >= the largest of dims, <= 1024); positions wrapped into the orthorhombic frame of `box`. */
 int azp_sorter_keys(uint32_t n, const double* d_pos, const azp_box* box, const uint32_t* dims, uint32_t block, int32_t* d_keys,
                     void* stream);
 
