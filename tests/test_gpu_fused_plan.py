@@ -475,3 +475,24 @@ def test_fused_plan_random_systems(oracle, seed):
     assert_close(out[1], v_ref, what="seed %d virial" % seed)
     extra = info["n_neigh"].astype(np.int64) - nl[0].astype(np.int64)
     assert extra.min() >= 0 and extra.sum() <= 1e-3 * max(nl[0].sum(), 1000)
+
+
+def test_fused_plan_many_types(oracle):
+    """Ten particle types: the compiler reads its per-type-pair tables from memory (they are cached in
+    LDS only up to eight types) and classes come from the formula, not from the r^2 table."""
+    T = 10
+    pos, L, typeid = H.lattice_config(15, 1.1, 0.11, seed=23, ntypes=T)
+    box = oracle.make_box(L)
+    r_cut = np.full((T, T), 2.5)
+    for i in range(T):
+        for j in range(i, T):
+            r_cut[i, j] = r_cut[j, i] = 2.5 - 0.07 * ((i * 3 + j) % 8)
+    tab = H.sym_table(T, lambda i, j: dict(epsilon=1.0 + 0.05 * (i + j), sigma=1.0 - 0.01 * (i + j), attraction_scale_factor=0.1 + 0.04 * min(i, j)))
+    params = np.array([oracle.pack_pair_params(PLJ, tab[i][j]) for i in range(T) for j in range(T)])
+    nl = oracle.build_nlist(pos, box, r_cut + 0.3, ntypes=T)
+    f_ref, v_ref = oracle.pair_forces(PLJ, pos, box, nl, params, r_cut, 0.0, "shift", ntypes=T, virial=True)
+    for balance in (False, True):
+        (f_gpu, v_gpu), info = fused_forces(PLJ, pos, (L,), params, r_cut, 0.3, ntypes=T, mode="shift", virial=True, balance=balance)
+        assert info["valid"] == 1 and info["from_cells"] == 1
+        assert_close(f_gpu, f_ref)
+        assert_close(v_gpu, v_ref, what="virial")
