@@ -77,6 +77,12 @@ pc += ["", "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them, uncorrecte
        "SQ_LDS_IDX_ACTIVE / 256 CUs = %.2f M cycles: the per-lane LDS reads of the staged candidates are the co-limit." % (vals.get("SQ_LDS_IDX_ACTIVE", 0) / 256 / 1e6)]
 pc += ["", "Experiments on the final kernel that changed nothing (same box, 1.37-1.41 ms): three workgroups per CU instead of four",
        "(4 KiB of padding in LDS), candidates as 16-byte records read with `ds_read_b128` instead of three `ds_read2_b32`, 16 raw",
-       "entries in flight in the row walks instead of 8, XCD-aware tile order. 2,048 candidates per batch (two workgroups per CU): 1.72 ms."]
+       "entries in flight in the row walks instead of 8, XCD-aware tile order. 2,048 candidates per batch (two workgroups per CU): 1.72 ms.",
+       "",
+       "One that changed the wrong thing: batches made of every n-th cell of the sorted cell array instead of contiguous ranges (in a",
+       "liquid a contiguous range is a slab of space that only some of the four waves' members are next to: 1.44x the mean wave's work per",
+       "batch against 1.04x). The build of the melted system went from 1.68 to 1.54 ms, the MD step from 0.453 to 0.476 ms: the rows then list",
+       "their entries batch by batch instead of in ascending slot order, and the force kernel, LDS-bound as much as VALU-bound, pays more",
+       "for that than the build saves. Not kept."]
 open(os.path.join(P, "r02_plan_cells.md"), "w").write("\n".join(pc) + "\n")
 print("\n".join(pc))
