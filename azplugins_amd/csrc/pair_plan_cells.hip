@@ -497,7 +497,7 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
                 if (!SINGLE)
                     {
                     tpa = trow + ctype[c];
-                    tpb = trow + ctype[c + 1u];
+                    tpb = trow + (second ? (uint32_t)ctype[c + 1u] : 0u); // (the pad entry holds no type: its byte must not index a table)
                     rla = rc_cached ? s_rlistsq[tpa] : (a.rlistsq[tpa] > 0.0 ? (float)a.rlistsq[tpa] * 1.00001f : -1.f);
                     rlb = rc_cached ? s_rlistsq[tpb] : (a.rlistsq[tpb] > 0.0 ? (float)a.rlistsq[tpb] * 1.00001f : -1.f);
                     rla = rla > 0.f ? rla + rl_extra : rla;
