@@ -252,6 +252,7 @@ SYMBOLS = {
     "azp_spherical_barrier_valid": (C.c_int, [_D, C.POINTER(Box)]),
     "azp_integrate_nve_step_one": (C.c_int, [C.POINTER(NVEArgs), _VP]),
     "azp_integrate_nve_step_two": (C.c_int, [C.POINTER(NVEArgs), _VP]),
+    "azp_integrate_nve_step_two_one": (C.c_int, [C.POINTER(NVEArgs), _VP]),
     "azp_integrate_nve_rot_step_one": (C.c_int, [C.POINTER(NVERotArgs), _VP]),
     "azp_integrate_nve_rot_step_two": (C.c_int, [C.POINTER(NVERotArgs), _VP]),
     "azp_version": (C.c_int, []),

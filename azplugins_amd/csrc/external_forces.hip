@@ -136,8 +136,13 @@ struct NVEKArgs
     uint32_t N;
     };
 
-template<bool STEP_ONE> __global__ void __launch_bounds__(256) nve_kernel(const NVEKArgs a)
+// MODE 0: step two (v += a dt/2). 1: step one (v += a dt/2, x += v dt, wrap). 2: step two of one step and step
+// one of the next in one pass over the arrays -- the two half kicks use the same force (no force evaluation lies
+// between them) and are applied one after the other exactly as the two kernels apply them: bit-identical, 184
+// instead of 280 bytes per particle.
+template<int MODE> __global__ void __launch_bounds__(256) nve_kernel(const NVEKArgs a)
     {
+    constexpr bool STEP_ONE = MODE != 0;
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= a.N)
         return;
@@ -145,6 +150,10 @@ template<bool STEP_ONE> __global__ void __launch_bounds__(256) nve_kernel(const 
     const double4 f = load_scalar4(a.net_force, idx);
     const double minv = 1.0 / v.w;
     const double hdt = 0.5 * a.dt;
+    if (MODE == 2)
+        {
+        v.x += hdt * f.x * minv; v.y += hdt * f.y * minv; v.z += hdt * f.z * minv;
+        }
     v.x += hdt * f.x * minv; v.y += hdt * f.y * minv; v.z += hdt * f.z * minv;
     store_scalar4(a.vel, idx, v.x, v.y, v.z, v.w);
     if (STEP_ONE)
@@ -168,7 +177,7 @@ template<bool STEP_ONE> __global__ void __launch_bounds__(256) nve_kernel(const 
         }
     }
 
-template<bool STEP_ONE> static int launch_nve(const azp_nve_args* args, void* stream)
+template<int MODE> static int launch_nve(const azp_nve_args* args, void* stream)
     {
     if (!args)
         return AZP_ERROR_INVALID_ARGUMENT;
@@ -188,7 +197,7 @@ template<bool STEP_ONE> static int launch_nve(const azp_nve_args* args, void* st
     k.dt = args->dt;
     k.N = args->N;
     const uint32_t grid = (args->N + bs - 1) / bs;
-    hipLaunchKernelGGL(nve_kernel<STEP_ONE>, dim3(grid), dim3(bs), 0, static_cast<hipStream_t>(stream), k);
+    hipLaunchKernelGGL(nve_kernel<MODE>, dim3(grid), dim3(bs), 0, static_cast<hipStream_t>(stream), k);
     return (int)hipGetLastError();
     }
 } // namespace azp
@@ -203,11 +212,15 @@ extern "C" int azp_external_spherical_harmonic_barrier(const azp_barrier_args* a
     }
 extern "C" int azp_integrate_nve_step_one(const azp_nve_args* args, void* stream)
     {
-    return azp::launch_nve<true>(args, stream);
+    return azp::launch_nve<1>(args, stream);
     }
 extern "C" int azp_integrate_nve_step_two(const azp_nve_args* args, void* stream)
     {
-    return azp::launch_nve<false>(args, stream);
+    return azp::launch_nve<0>(args, stream);
+    }
+extern "C" int azp_integrate_nve_step_two_one(const azp_nve_args* args, void* stream)
+    {
+    return azp::launch_nve<2>(args, stream);
     }
 
 // src/PlanarBarrierEvaluator.h:50-55: H inside [lo.y, hi.y), lo / hi = box.makeCoordinates((0,0,0)) /

@@ -203,11 +203,18 @@ class Simulation:
             _lib.check(fn(C.byref(rot), stream), "azp_integrate_nve_rot_step")
             return torque
 
-        for _ in range(steps):
-            # velocity Verlet (libazp kernels): v += a dt/2, x += v dt, wrap | forces | v += a dt/2
+        for k in range(steps):
+            # velocity Verlet (libazp kernels): v += a dt/2, x += v dt, wrap | forces | v += a dt/2. Inside a run
+            # nothing reads the velocities between step two of one step and step one of the next: they are one
+            # kernel (same arithmetic, one pass over the arrays); the last step two comes after the loop
             point_at_state()
-            _lib.check(lib.azp_integrate_nve_step_one(C.byref(a), stream), "azp_integrate_nve_step_one")
+            if k == 0:
+                _lib.check(lib.azp_integrate_nve_step_one(C.byref(a), stream), "azp_integrate_nve_step_one")
+            else:
+                _lib.check(lib.azp_integrate_nve_step_two_one(C.byref(a), stream), "azp_integrate_nve_step_two_one")
             if rot is not None:
+                if k:
+                    rotational_step(False)  # (step two of the previous step: the torques are still its own)
                 rotational_step(True)
             if self.domain is not None:
                 self.domain.exchange(self._halo_fields())  # ghost rows follow their owners' particles
@@ -220,10 +227,10 @@ class Simulation:
                 if tuner.trigger_period > 0 and self.timestep % tuner.trigger_period == 0 and st.n_ghost == 0:
                     tuner.sort(self)
             self._compute_forces()
-            point_at_state()
-            _lib.check(lib.azp_integrate_nve_step_two(C.byref(a), stream), "azp_integrate_nve_step_two")
-            if rot is not None:
-                rotational_step(False)
+        point_at_state()
+        _lib.check(lib.azp_integrate_nve_step_two(C.byref(a), stream), "azp_integrate_nve_step_two")
+        if rot is not None:
+            rotational_step(False)
 
     def kinetic_temperature(self):
         """Instantaneous kT = 2 KE / (3 N - 3) (HOOMD ThermodynamicQuantities)."""

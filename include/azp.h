@@ -503,6 +503,10 @@ typedef struct azp_nve_args
 
 int azp_integrate_nve_step_one(const azp_nve_args* args, void* stream);
 int azp_integrate_nve_step_two(const azp_nve_args* args, void* stream);
+/* Step two of one time step and step one of the next in one kernel: for a loop in which nothing reads the
+ * velocities between the two (HOOMD calls integrateStepTwo and the next integrateStepOne back to back unless an
+ * updater or analyzer is due). Same arithmetic in the same order as the two calls, one pass over the arrays. */
+int azp_integrate_nve_step_two_one(const azp_nve_args* args, void* stream);
 
 /* Rotational degrees of freedom of the same step ("+ rotational for
  * aniso"; the reference's aniso test gives its particles a moment of inertia,

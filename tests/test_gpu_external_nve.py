@@ -258,3 +258,41 @@ def test_two_patch_morse_nve_with_rotation_conserves_energy():
         assert np.allclose(np.linalg.norm(q, axis=1), 1.0, atol=1e-12)
     for dt, (e0, e1, kt0, kr1) in energies.items():
         assert abs(e1 - e0) < 5e-3 * kt0, "dt=%g: energy drift %g vs K_trans(0) %g" % (dt, e1 - e0, kt0)
+
+
+def test_nve_step_two_one_is_step_two_then_step_one():
+    """azp_integrate_nve_step_two_one (what Simulation.run launches between two force evaluations) leaves
+    exactly the bits that azp_integrate_nve_step_two followed by azp_integrate_nve_step_one leave: positions,
+    velocities, images, particles wrapped through the periodic boundary included."""
+    import ctypes as C
+
+    import torch
+
+    from azplugins_amd import _lib
+
+    n = 5000
+    tag = np.arange(n, dtype=np.uint64)
+    L = 7.0
+    pos = np.stack([(syn.u01(1, tag, c) - 0.5) * L for c in range(3)] + [np.zeros(n)], axis=1)
+    vel = np.stack([syn.normal(2, tag, c) * 3.0 for c in range(3)] + [0.5 + syn.u01(3, tag, 0)], axis=1)  # w = mass
+    frc = np.stack([syn.normal(4, tag, c) * 50.0 for c in range(4)], axis=1)
+    results = []
+    for fused in (False, True):
+        t = dict(pos=torch.from_numpy(pos.copy()).to("cuda:0"), vel=torch.from_numpy(vel.copy()).to("cuda:0"),
+                 frc=torch.from_numpy(frc.copy()).to("cuda:0"), image=torch.zeros((n, 3), dtype=torch.int32, device="cuda:0"))
+        a = _lib.NVEArgs()
+        a.d_pos, a.d_vel, a.d_net_force, a.d_image = t["pos"].data_ptr(), t["vel"].data_ptr(), t["frc"].data_ptr(), t["image"].data_ptr()
+        a.box = _lib.make_box(L)
+        a.dt = 0.05
+        a.N = n
+        lib = _lib.lib()
+        if fused:
+            _lib.check(lib.azp_integrate_nve_step_two_one(C.byref(a), None), "two_one")
+        else:
+            _lib.check(lib.azp_integrate_nve_step_two(C.byref(a), None), "two")
+            _lib.check(lib.azp_integrate_nve_step_one(C.byref(a), None), "one")
+        torch.cuda.synchronize()
+        results.append({k: v.cpu().numpy().copy() for k, v in t.items()})
+    for k in ("pos", "vel", "image"):
+        assert np.array_equal(results[0][k], results[1][k]), k
+    assert np.abs(results[0]["image"]).sum() > 0   # some particles did cross the boundary
