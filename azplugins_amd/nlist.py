@@ -147,16 +147,22 @@ class Cell(NeighborList):
         largest displacement since the build (``displacement_bound``)."""
         import torch
 
+        # [flag, max |dx|^2 bits] per check, a ring of 64 rows zeroed once per 64 checks (not a fill kernel per step)
         if getattr(self, "_flag", None) is None or self._flag.device != state.pos.device:
-            self._flag = torch.zeros(2, dtype=torch.int64, device=state.pos.device)  # [flag, max |dx|^2 bits]
-        self._flag.zero_()
+            self._flag = torch.zeros((64, 2), dtype=torch.int64, device=state.pos.device)
+            self._flag_i = 0
+        if self._flag_i == 64:
+            self._flag.zero_()
+            self._flag_i = 0
+        row = self._flag[self._flag_i]
+        self._flag_i += 1
         box = state.box.to_c()
         stream = _lib.raw_stream(state.device)
         _lib.check(_lib.lib().azp_nlist_distance_check(state.n_max, state.pos.data_ptr(), self._pos_at_build.data_ptr(),
-                                                       C.byref(box), (0.5 * self.buffer) ** 2, self._flag.data_ptr(),
-                                                       self._flag.data_ptr() + 8, stream),
+                                                       C.byref(box), (0.5 * self.buffer) ** 2, row.data_ptr(),
+                                                       row.data_ptr() + 8, stream),
                    "azp_nlist_distance_check")
-        flag, bits = self._flag.tolist()
+        flag, bits = row.tolist()
         self._disp = float(np.sqrt(np.array([bits], dtype=np.int64).view(np.float64)[0]))
         self._disp_generation = state.position_generation
         return bool(flag)
