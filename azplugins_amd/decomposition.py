@@ -144,7 +144,9 @@ class RankDomain:
         interior = interior[np.argsort(_blocked_key(xyz_global[interior], lo_int, hi - lo_int, density), kind="stable")]
         boundary = boundary[np.argsort(_blocked_key(xyz_global[boundary], lo, hi - lo, density), kind="stable")]
         self.local_gid = np.concatenate([interior, boundary])
-        self.n_interior = int(interior.size)
+        # whole tiles of 256: the interior launch then stages interior tiles only (its LDS variant is picked from
+        # the largest staged set of ITS tiles); the odd interior particles are computed with the boundary
+        self.n_interior = int(interior.size) // 256 * 256
         shell = decomp.in_ghost_shell(xyz_global, rank)
         ghost_mask = shell & (owner != rank)
         ghost_gid = np.flatnonzero(ghost_mask)

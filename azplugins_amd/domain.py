@@ -213,7 +213,9 @@ class DeviceDomain:
         perm = torch.sort(key, stable=True).indices
         for n in self.names:
             new[n] = new[n].index_select(0, perm)
-        self.n_interior = int((~shell).sum().item())
+        # whole tiles of 256 (cf. decomposition.RankDomain): the tile that mixes interior and boundary particles, with
+        # its large staged set, belongs to the boundary launch
+        self.n_interior = int((~shell).sum().item()) // 256 * 256
         self.N_local = n_new
         # 3. ghosts: per peer, my boundary particles inside its ghost shell (ascending local index)
         xyz_b = new["pos"][self.n_interior:, :3]

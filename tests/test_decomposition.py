@@ -107,7 +107,9 @@ def _worker(rank, world, port, out_dir):
     # since, so test the ones that are still deeper than the list radius)
     n_neigh, head, nlist = nl
     assert np.all(dec.depth(cfg["xyz"][dom.local_gid[: dom.n_interior]], rank) >= dec.r_ghost)
-    assert np.all(dec.depth(cfg["xyz"][dom.local_gid[dom.n_interior:]], rank) < dec.r_ghost)
+    # (whole tiles of 256 only: up to 255 interior particles are computed with the boundary)
+    deep = dec.depth(cfg["xyz"][dom.local_gid[dom.n_interior:]], rank) >= dec.r_ghost
+    assert dom.n_interior % 256 == 0 and deep.sum() < 256 and not deep[deep.sum():].any()
     deep = np.flatnonzero(dec.depth(pos[: dom.N_local, :3].numpy(), rank) >= dec.r_ghost)
     for i in deep:
         assert (nlist[int(head[i]): int(head[i]) + int(n_neigh[i])] < dom.N_local).all()
