@@ -368,7 +368,14 @@ def bench_main(args, rank, world, local_rank):
         dt = 0.005
         extra = 0
     pot.params[("A", "A")] = cfg["params"]
-    pot.threads_per_particle = args.tpp
+    # tile size, as HOOMD's autotuner picks threads_per_particle for the kernel alone (the list is static here):
+    # a rank with few particles fills the GPU better with tiles of 64 / 128 particles (4 / 2 lanes per particle;
+    # rank 0 of 8 at N = 2^20: interior + boundary 45 -> 31 us, of 4: 58 -> 48 us, tools/dd_plan_check.py --strong).
+    # An MD run keeps tiles of 256, whose plan comes straight from the cell list (cheaper rebuilds).
+    tpp = args.tpp
+    if tpp == 0 and kind == "plj":
+        tpp = 4 if dom.N_local < 200_000 else (2 if dom.N_local < 400_000 else 0)
+    pot.threads_per_particle = tpp
     pot.block_size = args.block_size
     pot.use_plan = not args.no_plan
     # the list is static here (no integration), which would let the tile kernel stop its rows at

@@ -21,6 +21,8 @@ from azplugins_amd.decomposition import Decomposition, HaloExchange, build_rank_
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--worlds", default="2,4,8")
+ap.add_argument("--tpp", type=int, default=0, help="threads per particle of the tile kernel (0: the library's choice; 2, 4: list-based plan, smaller tiles)")
+ap.add_argument("--strong", action="store_true", help="the north star's own 2^20 particles cut into `world` sub-boxes (default: 2^20 per rank)")
 args = ap.parse_args()
 
 
@@ -37,7 +39,7 @@ def timed(fn, reps=50):
 
 for world in [int(w) for w in args.worlds.split(",")]:
     grid = choose_grid(world, np.ones(3))
-    cfg = syn.config_north_star(tuple(64 * g for g in grid))
+    cfg = syn.config_north_star(64) if args.strong else syn.config_north_star(tuple(64 * g for g in grid))
     decomp = Decomposition(cfg["L"], world, cfg["r_cut"] + cfg["r_buff"], grid=grid)
     dom, state = build_rank_state(cfg, decomp, 0, "cuda:0")
     halo = HaloExchange(dom, "cuda:0")
@@ -46,6 +48,7 @@ for world in [int(w) for w in args.worlds.split(",")]:
     nl = azp.nlist.Cell(buffer=cfg["r_buff"])
     pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=cfg["r_cut"])
     pot.params[("A", "A")] = cfg["params"]
+    pot.threads_per_particle = args.tpp
     sim.operations.integrator = azp.Integrator(dt=0.005, forces=[pot])
     sim.run(0)
     n_int, n_bnd = dom.n_interior, dom.N_local - dom.n_interior
