@@ -83,6 +83,11 @@ pc += ["", "Experiments on the final kernel that changed nothing (same box, 1.37
        "liquid a contiguous range is a slab of space that only some of the four waves' members are next to: 1.44x the mean wave's work per",
        "batch against 1.04x). The build of the melted system went from 1.68 to 1.54 ms, the MD step from 0.453 to 0.476 ms: the rows then list",
        "their entries batch by batch instead of in ascending slot order, and the force kernel, LDS-bound as much as VALU-bound, pays more",
-       "for that than the build saves. Not kept."]
+       "for that than the build saves. Not kept.",
+       "",
+       "And one that bought robustness at a price: 1,024 instead of 512 cells around a tile with a 16-bit run table (first cell | length;",
+       "the candidate bounds then come from two more LDS reads at every run transition). The thin boundary shells of a decomposed DPD fluid",
+       "then compile from the cells too, but the build of the north-star system goes from 1.40 to 1.45 ms (liquid: 1.63 to 1.68). Not kept:",
+       "those tiles fall back to the list-based compiler, which handles them."]
 open(os.path.join(P, "r02_plan_cells.md"), "w").write("\n".join(pc) + "\n")
 print("\n".join(pc))
