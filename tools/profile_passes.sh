@@ -5,6 +5,8 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out/r02w
 mkdir -p $O
 export TMPDIR=/tmp
+# the profiling build of the library for the phase-by-phase figures of plan_cells_kernel
+make -C azplugins_amd/csrc variant SRC=pair_plan_cells NAME=pcprof DEFS=-DAZP_PLAN_CELLS_PROFILE > $O/pcprof_build.log 2>&1
 B="python3 bench.py --no-cpu-baseline --no-side-figures --steps 80 --warmup 8"
 rocprofv3 --kernel-trace --stats -d $O/bench_stats --output-format csv -- $B > $O/bench_stats.json 2> $O/bench_stats.err
 echo "bench stats pass done"
