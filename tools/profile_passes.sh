@@ -1,8 +1,8 @@
 # The rocprofv3 passes behind profiles/r02_*: run on a GPU box from the repository root
-# (gpurun -- bash tools/profile_passes.sh); summaries are then condensed into profiles/ by hand.
+# (gpurun -- bash tools/profile_passes.sh); then python3 tools/condense_profiles.py gpurun_out/r02final writes the summaries under profiles/.
 set -e
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r02w
+O=gpurun_out/r02final
 mkdir -p $O
 export TMPDIR=/tmp
 # the profiling build of the library for the phase-by-phase figures of plan_cells_kernel
