@@ -85,7 +85,7 @@ def displace_particles(state, amplitude, seed):
     state.position_generation += 1
 
 
-def cpu_baseline(workload, reps=3):
+def cpu_baseline(workload, reps=3, gpu_forces_by_tag=None):
     """HOOMD-equivalent CPU loop restated (oracle): half neighbor list, third-law
     scatter, FP64, ONE core (HOOMD's per-rank CPU execution model), timed on
     this host on the workload itself (the full N; ~1 s per repetition)."""
@@ -99,13 +99,22 @@ def cpu_baseline(workload, reps=3):
     ts = []
     for _ in range(reps):
         t0 = time.perf_counter()
-        oracle.pair_forces(cfg["potential"], pos, box, nl, params, cfg["r_cut"], mode="none", half=True)
+        f_cpu = oracle.pair_forces(cfg["potential"], pos, box, nl, params, cfg["r_cut"], mode="none", half=True)
         ts.append(time.perf_counter() - t0)
     t = float(np.median(ts))
     N = pos.shape[0]
+    checked = None
+    if gpu_forces_by_tag is not None:
+        # the oracle is the checker here, never the thing measured: the forces the GPU path produced for
+        # cycle step 0 (= the workload's snapshot) against the CPU loop's, every particle
+        checked = float(np.abs(gpu_forces_by_tag - f_cpu).max() / np.abs(f_cpu).max())
+        if not (checked < 1e-10):
+            raise SystemExit("bench.py: GPU forces differ from the CPU oracle on the workload snapshot: %g" % checked)
     out = dict(value=N / t, unit="particle-steps/s", cores=1, kind="port",
                sample="%s: the workload itself, N=%d, half list (built outside the timed region), median of %d "
                       "repetitions of the force loop; oracle = HOOMD-equivalent loop restated, not the HOOMD binary" % (cfg["name"], N, reps))
+    if checked is not None:
+        out["gpu_vs_cpu_max_abs_err_over_max_force"] = checked
     del nl
     # best-effort all-core figure (OpenMP over particles, full list), on this process's CPU share
     try:
@@ -185,6 +194,13 @@ def main():
     ap.add_argument("--static", action="store_true",
                     help="time only the snapshot the list was built for (displacement bound 0: round 1's headline state) "
                          "instead of a rebuild cycle of an MD run")
+    ap.add_argument("--settle-ms", type=float, default=80.0,
+                    help="untimed run-in before the W warmup steps: the same launches on the same cycle states, back to back, for this "
+                         "many milliseconds, so that the timed region sits at the clock the chip SUSTAINS under this kernel (as "
+                         "in an MD run of millions of steps) and not in the power controller's transient: from idle the first "
+                         "~1 ms runs at boost clock, launches 15-50 run up to 35 %% slower, and the clock settles over ~50 ms "
+                         "(profiles/r03_clock_transient.md). 0 = none")
+    ap.add_argument("--no-verify", action="store_true", help="skip the check of the timed states' forces after the timed region")
     ap.add_argument("--kT", type=float, default=1.0, help="temperature of the Maxwell velocities that drive the recorded MD cycle")
     ap.add_argument("--bank-order", type=int, default=0,
                     help="1: bank-aware row order in the tile plan (what a list that lives >= 50 force calls gets); "
@@ -195,6 +211,8 @@ def main():
                          "the metric is defined; 1 = the moment before the next rebuild)")
     ap.add_argument("--no-fused-plan", action="store_true",
                     help="build HOOMD's u32 neighbor list and compile the tile plan from it (default: plan straight from the cell list)")
+    ap.add_argument("--balance", type=int, default=-1,
+                    help="1 / 0: rows of a tile to its lanes by in-range length (balanced plans) on / off; default: the class's own choice")
     ap.add_argument("--sort-rows", action="store_true", help="experiment: sort every neighbor row by index before planning")
     ap.add_argument("--no-displacement-bound", action="store_true",
                     help="do not tell the planned kernel how far particles moved since the list was built (it then walks "
@@ -234,6 +252,8 @@ def main():
     pot.threads_per_particle = args.tpp
     pot.block_size = args.block_size
     pot.use_plan = not args.no_plan
+    if args.balance >= 0:
+        pot._plan_balance = bool(args.balance)
     pot.use_displacement_bound = not args.no_displacement_bound
     sim.operations.integrator = azp.Integrator(dt=0.005, forces=[pot])
     if args.sort_rows or args.no_fused_plan:
@@ -299,6 +319,22 @@ def main():
             step.current = s
         pot.compute(0)
 
+    # run-in (untimed, before the W warmup steps): the cycle walked back to back until the chip's
+    # power controller has settled (--settle-ms)
+    def settle():
+        n = 0
+        if args.settle_ms > 0.0:
+            per_pass = 8 * n_states
+            t_settle = time.perf_counter()
+            while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+                step.current = -1
+                for k in range(per_pass):
+                    step(k, per_pass)
+                torch.cuda.synchronize()
+                n += per_pass
+        return n
+
+    settle_launches = settle()
     step.current = -1
     for k in range(args.warmup):
         step(k, args.warmup)
@@ -316,6 +352,34 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
     ms_per_step = wall * 1e3 / args.steps
 
+    # ---- check of what the timed region computed (outside it): the forces the timed launches left
+    # behind for the LAST cycle state, and those of every other cycle state recomputed the same way
+    # (same plan, same assumed displacement bound), must be bit-identical to a launch that is told
+    # nothing about displacements and walks whole rows (the kernel's cutoff test is exact either way;
+    # tests/test_gpu_full_size.py checks whole rows against the oracle at this size)
+    verified = None
+    f_state0 = None
+    if not args.no_verify and pot.use_plan:
+        timed_last = pot.force_tensor.clone()
+        verified = True
+        for k in reversed(range(n_states)):
+            set_state(k)
+            pot.compute(0)
+            with_bound = pot.force_tensor.clone()
+            if k == n_states - 1:
+                verified = verified and bool((with_bound == timed_last).all())
+            pot.use_displacement_bound = False
+            pot.compute(0)
+            pot.use_displacement_bound = not args.no_displacement_bound
+            verified = verified and bool((pot.force_tensor == with_bound).all()) and bool(torch.isfinite(with_bound).all())
+            if k == 0 and n_states > 1 and args.mode == "none":  # kept for the CPU oracle's check in cpu_baseline (by tag)
+                f_state0 = np.empty((N, 4))
+                f_state0[st.tag[:N].cpu().numpy().view(np.uint32)] = with_bound.cpu().numpy()
+            del with_bound
+        if not verified:
+            raise SystemExit("bench.py: the forces of the timed states differ from the whole-row evaluation")
+        step.current = -1
+
     # ---- side figures, outside the timed region (>= 40 launches each) ----
     def timed(reps=40):
         pot.compute(0)
@@ -328,6 +392,8 @@ def main():
         return e0.elapsed_time(e1) / reps
 
     by_step = []
+    if not args.no_side_figures:
+        settle()  # the side figures too are taken at the sustained clock
     for k in range(n_states):
         if args.no_side_figures:
             break
@@ -403,6 +469,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
+        "verified": verified,
         "config": {
             "workload": "%s: PerturbedLennardJones N=%d rho*=0.8 r_cut=%.1f buffer=%.1f mode=%s, jittered %s lattice, "
                         "full neighbor list <n>=%.2f" % (cfg["name"], N, cfg["r_cut"], r_buff, args.mode,
@@ -410,6 +477,8 @@ def main():
             "N": N,
             "mean_neighbors": mean_neigh,
             "states_timed": cycle_desc,
+            "settle": "untimed run-in before the warmup: %d launches walking the same cycle back to back (%.0f ms), so that the "
+                      "timed region runs at the sustained clock, not in the power controller's start-up transient" % (settle_launches, args.settle_ms),
             "kernel_ms_by_cycle_step": by_step,
             "kernel_ms_other_states": side,
             "plan_bank_order": bool(pot.plan_bank_order) if n_states > 1 else None,
@@ -446,7 +515,7 @@ def main():
                     "under this load",
         }
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.workload)
+        out["cpu_baseline"] = cpu_baseline(args.workload, gpu_forces_by_tag=f_state0)
         out["cpu_baseline"]["gpu_over_cpu_1core"] = value / out["cpu_baseline"]["value"]
     print(json.dumps(out))
 
