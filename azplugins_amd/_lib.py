@@ -150,6 +150,8 @@ class PlanInfo(C.Structure):
         ("list_id", C.c_uint64),
         ("head_id", C.c_uint64),
         ("balanced", C.c_int32),
+        ("core_radius", C.c_float),
+        ("sure_radius", C.c_float),
         ("_pad", C.c_int32),
     ]
 
@@ -224,6 +226,7 @@ SYMBOLS = {
     "azp_pair_plan_set_balance": (C.c_int, [_VP, C.c_int]),
     "azp_pair_plan_tile_stage": (C.c_int, [_VP, C.POINTER(C.c_uint32), C.c_uint32]),
     "azp_pair_plan_query": (C.c_int, [_VP, C.POINTER(PlanInfo)]),
+    "azp_pair_plan_phase_chunks": (C.c_int, [_VP, C.POINTER(C.c_float)]),
     "azp_pair_auto_plan_get_stats": (None, [C.POINTER(AutoPlanStats)]),
     "azp_pair_auto_plan_clear": (None, []),
     "azp_pair_forces_planned_perturbed_lennard_jones": (C.c_int, [_VP, C.POINTER(PairArgs), _VP, _VP]),
@@ -367,6 +370,12 @@ class PairPlan:
         i = PlanInfo()
         check(lib().azp_pair_plan_query(self._h, C.byref(i)), "azp_pair_plan_query")
         return {f[0]: getattr(i, f[0]) for f in PlanInfo._fields_ if f[0] != "_pad"}
+
+    def phase_chunks(self):
+        """Diagnostics: mean chunks per slice covering the core entries / up to the end of the all-sure part / whole rows."""
+        out = (C.c_float * 3)()
+        check(lib().azp_pair_plan_phase_chunks(self._h, out), "azp_pair_plan_phase_chunks")
+        return [float(x) for x in out]
 
     @property
     def handle(self):

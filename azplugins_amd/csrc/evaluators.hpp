@@ -152,6 +152,17 @@ struct EvalPLJ
         if (count_in)
             n_in += in ? 1u : 0u;
         }
+    // A pair that is certainly inside the cutoff and outside the core (tile kernel, row phase "sure":
+    // the plan's row classes and the caller's displacement bound say so): the tail form without its mask.
+    static __device__ __forceinline__ void eval_split_sure(const Coeff& c, double x, double& force_divr, double& s1, double& s2)
+        {
+        const double r6inv = x * x * x;
+        force_divr = x * r6inv * __builtin_fma(c.c12_lam, r6inv, -c.c6_lam);
+        s2 = __builtin_fma(r6inv, r6inv, s2);
+        s1 += r6inv;
+        }
+    // radius of the core (the separation below which in_core holds)
+    static __device__ __forceinline__ double core_radius(const Coeff& c) { return sqrt(c.wca_rsq); }
     static __device__ __forceinline__ double finish_split(const Coeff& c, double pe_raw, double s1, double s2, uint32_t n_wca,
                                                           uint32_t n_in)
         {

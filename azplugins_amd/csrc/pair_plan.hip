@@ -31,6 +31,8 @@ struct PlanKArgs
     const double* rcutsq;
     const double* rinnersq; // optional (may be null): "core" class radius^2 per type pair
     uint32_t* slice_Kend;   // PLAN_SHELLS + 1 per slice, zeroed before the build kernel
+    uint32_t* slice_Kphase; // [2][n_slices]: core chunks (zeroed before the build kernel), sure chunks (set to ~0 before it)
+    uint32_t n_slices;
     double r_list_max;      // caller's hint (r_cut_max + 2 r_buff), 0 = unknown
     double r_list_estimate; // used when r_list_max is unknown: an estimate of r_cut_max + r_buff (0: one shell holds
                             // the whole buffer)
@@ -136,6 +138,7 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
     float4* s_p = reinterpret_cast<float4*>(list);
     __shared__ uint32_t s_n, s_overflow;
     __shared__ float s_shell_w;   // shell width w = r_buff / PLAN_SHELLS (0: no hint, no shells)
+    __shared__ float s_sure_rsq;  // one particle type: entries certainly closer than this form class sure (0: no such class)
     __shared__ float s_rcutsq[64], s_rinnersq[64], s_rcut[64]; // up to 8 types cached; more types read the global tables
     // bank-aware row ordering (TPP == 1): per wave 16 bank counters and one misfit counter
     // per class, and the list of unclaimed positions
@@ -165,8 +168,17 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
         const double w = (a.r_list_max > 0.0) ? 0.5 * (a.r_list_max - sqrt(rc_max_sq)) / PLAN_SHELLS
                                               : (a.r_list_estimate > 0.0 ? (a.r_list_estimate - sqrt(rc_max_sq)) / PLAN_SHELLS : 0.0);
         s_shell_w = (w > 0.0) ? (float)w : 0.f;
+        // class sure (pair_plan.hpp): closer than r_cut - r_buff, taken 2e-4 short for the single-precision separation;
+        // class core: what the force kernel may rely on is the inner radius less 1e-4
+        const float r_sure = (a.ntypes == 1 && w > 0.0) ? (float)(sqrt(rc_max_sq) - PLAN_SHELLS * w) - 2e-4f : 0.f;
+        s_sure_rsq = r_sure > 0.f ? r_sure * r_sure : 0.f;
         if (blockIdx.x == 0)
+            {
             a.flags[3] = (uint32_t)__float_as_int(s_shell_w);
+            a.flags[0] = (uint32_t)__float_as_int(r_sure > 0.f ? r_sure + 1e-4f : 0.f);
+            const float rin = (a.ntypes == 1 && a.rinnersq && a.rinnersq[0] > 0.0) ? (float)sqrt(a.rinnersq[0]) : 0.f;
+            a.flags[7] = (uint32_t)__float_as_int(rin > 0.f ? rin - 1e-4f : 0.f);
+            }
         }
     if (rc_cached && tid < a.ntypes * a.ntypes)
         {
@@ -383,14 +395,15 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
                     const float rcsq = rc_cached ? s_rcutsq[tp] : (float)a.rcutsq[tp];
                     const bool in = !(rsq >= rcsq * 1.0001f); // "inside, or too close to call"
                     if (in)
-                        cls = (rsq < (rc_cached ? s_rinnersq[tp] : (a.rinnersq ? (float)a.rinnersq[tp] : 0.f))) ? 0u : 1u;
+                        cls = (rsq < (rc_cached ? s_rinnersq[tp] : (a.rinnersq ? (float)a.rinnersq[tp] : 0.f)))
+                                  ? PLAN_CLS_CORE : (rsq < s_sure_rsq ? PLAN_CLS_SURE : PLAN_CLS_NEAR);
                     else
                         {
                         // shell s <=> the separation is certainly >= r_cut + s w: the single-precision
                         // r is shortened by 5e-5 (its own error is < 1e-5) before it is binned
                         const float rc = rc_cached ? s_rcut[tp] : sqrtf(fmaxf(rcsq, 0.f));
                         const float sh = floorf((sqrtf(rsq) * 0.99995f - rc) * shell_winv);
-                        cls = 2u + (uint32_t)fminf(fmaxf(sh, 0.f), (float)(PLAN_SHELLS - 1)); // NaN (w = 0) -> shell 0
+                        cls = PLAN_CLS_SHELL0 + (uint32_t)fminf(fmaxf(sh, 0.f), (float)(PLAN_SHELLS - 1)); // NaN (w = 0) -> shell 0
                         }
                     enc[it] = (((sidx + 1u) * 8u) << 4) | cls;
                     }
@@ -410,7 +423,10 @@ __global__ void __launch_bounds__(PLAN_BUILD_THREADS) plan_build_kernel(const Pl
             // entry up to the end of shell s [1 + s], over the rows of its slice
 #pragma unroll
             for (uint32_t sh = 0; sh <= PLAN_SHELLS; ++sh)
-                atomicMax(&a.slice_Kend[(PLAN_SHELLS + 1) * slice + sh], (seg[2 + sh] + 8u * TPP - 1u) / (8u * TPP));
+                atomicMax(&a.slice_Kend[(PLAN_SHELLS + 1) * slice + sh], (seg[PLAN_CLS_SHELL0 + sh] + 8u * TPP - 1u) / (8u * TPP));
+            // row phases of the force kernel: chunks that cover the core entries, chunks made of core / sure entries alone
+            atomicMax(&a.slice_Kphase[slice], (seg[PLAN_CLS_SURE] + 8u * TPP - 1u) / (8u * TPP));
+            atomicMin(&a.slice_Kphase[a.n_slices + slice], seg[PLAN_CLS_NEAR] / (8u * TPP));
             }
         if (TPP == 1 && PLAN_BANK_ORDER && a.bank_order)
             {
@@ -562,6 +578,7 @@ void plan_free(PairPlan& p)
     if (p.d_stage_idx) (void)hipFree(p.d_stage_idx);
     if (p.d_slice_K) (void)hipFree(p.d_slice_K);
     if (p.d_slice_Kend) (void)hipFree(p.d_slice_Kend);
+    if (p.d_slice_Kphase) (void)hipFree(p.d_slice_Kphase);
     if (p.d_slice_head) (void)hipFree(p.d_slice_head);
     if (p.d_cnl) (void)hipFree(p.d_cnl);
     if (p.d_flags) (void)hipFree(p.d_flags);
@@ -638,6 +655,7 @@ static int plan_build_tpp(PairPlan& p, const azp_pair_args& args, uint32_t tpp, 
     AZP_HIP_TRY(ensure(p.d_slice_K, p.cap_slices, p.n_slices));
     AZP_HIP_TRY(ensure(p.d_slice_Kend, p.cap_kend, (PLAN_SHELLS + 1) * (size_t)p.n_slices));
     AZP_HIP_TRY(ensure(p.d_slice_head, cap_heads_s, p.n_slices));
+    AZP_HIP_TRY(ensure(p.d_slice_Kphase, p.cap_kphase, 2 * (size_t)p.n_slices));
     size_t cap_flags = p.d_flags ? 8 : 0;
     AZP_HIP_TRY(ensure(p.d_flags, cap_flags, 8));
     AZP_HIP_TRY(hipMemsetAsync(p.d_flags, 0, 8 * sizeof(uint32_t), s));
@@ -650,6 +668,8 @@ static int plan_build_tpp(PairPlan& p, const azp_pair_args& args, uint32_t tpp, 
     k.rcutsq = args.d_rcutsq;
     k.rinnersq = args.d_rinnersq;
     k.slice_Kend = p.d_slice_Kend;
+    k.slice_Kphase = p.d_slice_Kphase;
+    k.n_slices = p.n_slices;
     // buffer shells: r_buff = (r_list_max - r_cut_max) / 2 is not known here, so the caller's
     // r_list_max hint and the largest cutoff are used when given
     k.r_list_max = args.r_list_max;
@@ -696,6 +716,8 @@ static int plan_build_tpp(PairPlan& p, const azp_pair_args& args, uint32_t tpp, 
         AZP_HIP_TRY(ensure(p.d_stage_idx, p.cap_stage, (size_t)p.n_tiles * stride));
         AZP_HIP_TRY(hipMemsetAsync(p.d_flags, 0, 8 * sizeof(uint32_t), s));
         AZP_HIP_TRY(hipMemsetAsync(p.d_slice_Kend, 0, (PLAN_SHELLS + 1) * sizeof(uint32_t) * p.n_slices, s));
+        AZP_HIP_TRY(hipMemsetAsync(p.d_slice_Kphase, 0, sizeof(uint32_t) * p.n_slices, s));
+        AZP_HIP_TRY(hipMemsetAsync(p.d_slice_Kphase + p.n_slices, 0xff, sizeof(uint32_t) * p.n_slices, s));
         k.stage_idx = p.d_stage_idx;
         k.cnl = p.d_cnl;
         k.stage_stride = stride;
@@ -725,6 +747,8 @@ static int plan_build_tpp(PairPlan& p, const azp_pair_args& args, uint32_t tpp, 
     p.shell_width = fm;
     __builtin_memcpy(&fm, &h_flags[4], sizeof(fm));
     p.max_listed_r = std::sqrt(fm);
+    __builtin_memcpy(&p.sure_r, &h_flags[0], sizeof(float));
+    __builtin_memcpy(&p.core_r, &h_flags[7], sizeof(float));
     }
     p.cap = plan_cap_for(p.max_stage);
     p.valid = true;
@@ -840,5 +864,31 @@ extern "C" int azp_pair_plan_query(const azp_pair_plan* plan, azp_pair_plan_info
     info->row_capacity = p->row_cap;
     info->list_id = reinterpret_cast<uint64_t>(p->nlist_ptr);
     info->head_id = reinterpret_cast<uint64_t>(p->head_ptr);
+    info->core_radius = p->core_r;
+    info->sure_radius = p->sure_r;
+    info->_pad = 0;
+    return AZP_SUCCESS;
+    }
+
+extern "C" int azp_pair_plan_phase_chunks(const azp_pair_plan* plan, float out[3])
+    {
+    if (!plan || !out)
+        return AZP_ERROR_INVALID_ARGUMENT;
+    const azp::PairPlan* p = reinterpret_cast<const azp::PairPlan*>(plan);
+    out[0] = out[1] = out[2] = 0.f;
+    if (!p->valid || !p->d_slice_Kphase || !p->n_slices)
+        return AZP_SUCCESS;
+    std::vector<uint32_t> h(3 * (size_t)p->n_slices);
+    AZP_HIP_TRY(hipMemcpy(h.data(), p->d_slice_Kphase, 2 * sizeof(uint32_t) * p->n_slices, hipMemcpyDeviceToHost));
+    AZP_HIP_TRY(hipMemcpy(h.data() + 2 * (size_t)p->n_slices, p->d_slice_K, sizeof(uint32_t) * p->n_slices, hipMemcpyDeviceToHost));
+    double s0 = 0, s1 = 0, s2 = 0;
+    for (uint32_t t = 0; t < p->n_slices; ++t)
+        {
+        const uint32_t K = h[2 * (size_t)p->n_slices + t], k0 = std::min(h[t], K), k1 = std::min(std::max(h[p->n_slices + t], k0), K);
+        s0 += k0; s1 += k1; s2 += K;
+        }
+    out[0] = (float)(s0 / p->n_slices);
+    out[1] = (float)(s1 / p->n_slices);
+    out[2] = (float)(s2 / p->n_slices);
     return AZP_SUCCESS;
     }

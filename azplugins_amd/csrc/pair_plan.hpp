@@ -40,7 +40,12 @@ constexpr uint32_t PLAN_ROWBUF = 512;         // compiled entries per row the bu
 constexpr double PLAN_FAR = 1.0e30;          // coordinate of the dummy slot
 constexpr uint32_t PLAN_SHELLS = 8;          // the Verlet-buffer entries of every row are ordered into this many shells
                                               // of equal width by their separation when the plan is built
-constexpr uint32_t PLAN_CLASSES = PLAN_SHELLS + 2; // row order: core | near | shell 0 | ... | shell PLAN_SHELLS - 1
+constexpr uint32_t PLAN_CLASSES = PLAN_SHELLS + 3; // row order: core | sure | near | shell 0 | ... | shell PLAN_SHELLS - 1
+constexpr uint32_t PLAN_CLS_CORE = 0;  // closer than the evaluator's inner radius hint (azp_pair_args.d_rinnersq) at build time
+constexpr uint32_t PLAN_CLS_SURE = 1;  // certainly closer than r_cut - r_buff at build time (one particle type only): such a pair
+                                       // stays inside the cutoff while no particle has moved farther than r_buff / 2
+constexpr uint32_t PLAN_CLS_NEAR = 2;  // inside the cutoff at build time, or too close to call
+constexpr uint32_t PLAN_CLS_SHELL0 = 3; // + s: certainly >= r_cut + s w away at build time
 
 struct PairPlan
     {
@@ -66,6 +71,12 @@ struct PairPlan
     uint32_t* d_slice_K = nullptr;         // n_slices
     uint32_t* d_slice_Kend = nullptr;      // (PLAN_SHELLS + 1) x n_slices: chunks up to the end of the in-range entries [0] /
                                            // of buffer shell s [1 + s]
+    uint32_t* d_slice_Kphase = nullptr;    // [2][n_slices]: chunks covering every entry of class core [0][slice]; chunks up to which
+                                           // every row of the slice holds only entries of the classes core and sure [1][slice]
+    size_t cap_kphase = 0;
+    float core_r = 0.f;                    // entries outside class core were at least this far apart at build time (the inner
+                                           // radius hint minus a margin for the single-precision test); 0: no core class
+    float sure_r = 0.f;                    // entries of class sure were at most this far apart (margin included); 0: no such class
     double shell_width = 0.0;              // w: shell s holds entries with r_build >= r_cut + s w (certainly); 0: no shells
                                            // (no r_list_max hint at build time: all buffer entries sit in shell 0)
     float max_listed_r = 0.f;              // largest separation of a listed pair when the plan was built (single precision)

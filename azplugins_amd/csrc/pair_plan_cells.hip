@@ -86,9 +86,10 @@ struct PlanCellsKArgs
     uint32_t* stage_idx;
     uint32_t* slice_K;
     uint32_t* slice_Kend;
+    uint32_t* slice_Kphase; // [2][n_slices]: chunks covering class core; chunks holding only core / sure entries in every row
     uint64_t* slice_head;
     uint4* cnl;
-    uint32_t* flags;        // [1] invalid, [2] max staged set, [3] shell width, [5] longest row, [6] reason
+    uint32_t* flags;        // [0] sure radius, [1] invalid, [2] max staged set, [3] shell width, [5] longest row, [6] reason, [7] core radius
     uint8_t* perm;          // balanced plans: lane -> member of the tile (n_tiles x 256); NULL: lane = member
     double r_list_max;
     BoxDev box;
@@ -142,14 +143,14 @@ __device__ __forceinline__ uint32_t set_insert(uint32_t* set, uint32_t size, uin
     return 2u;
     }
 
-// class of a listed pair at separation^2 rsq (pair_plan.hip): 0 core, 1 near (inside the cutoff or
-// too close to call), 2 + s buffer shell s <=> certainly >= r_cut + s w; rcsq_m = r_cut^2 * 1.0001,
-// rcw = r_cut / w, rscale = 0.99995 / w
+// class of a listed pair at separation^2 rsq (pair_plan.hpp): core, near (inside the cutoff or
+// too close to call), PLAN_CLS_SHELL0 + s buffer shell s <=> certainly >= r_cut + s w; rcsq_m = r_cut^2 * 1.0001,
+// rcw = r_cut / w, rscale = 0.99995 / w. (Class sure is cut out of near by the caller: it needs an UPPER bound on r.)
 __device__ __forceinline__ uint32_t pair_class(float rsq, float rcsq_m, float rin, float rcw, float rscale, float fmax_shell)
     {
     const float shf = floorf(__builtin_fmaf(__builtin_amdgcn_sqrtf(rsq), rscale, -rcw));
-    const uint32_t shell = 2u + (uint32_t)fminf(fmaxf(shf, 0.f), fmax_shell); // NaN (w = 0) -> shell 0
-    return !(rsq >= rcsq_m) ? ((rsq < rin) ? 0u : 1u) : shell;
+    const uint32_t shell = PLAN_CLS_SHELL0 + (uint32_t)fminf(fmaxf(shf, 0.f), fmax_shell); // NaN (w = 0) -> shell 0
+    return !(rsq >= rcsq_m) ? ((rsq < rin) ? PLAN_CLS_CORE : PLAN_CLS_NEAR) : shell;
     }
 
 template<bool SINGLE> // SINGLE: one particle type (cutoffs are constants, classes come from a table)
@@ -183,7 +184,7 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
     __shared__ uint32_t s_mcl[PC_MAXMC];                // the distinct cells of the members
     __shared__ uint32_t s_runs[PC_MAXMC][PC_RUNS];      // per member cell: candidate ranges, g0 | g1 << 16
     __shared__ unsigned char s_ctab[SINGLE ? PC_CTAB : 4];
-    __shared__ uint32_t s_kend[4][PLAN_SHELLS + 1], s_smax[4];
+    __shared__ uint32_t s_kend[4][PLAN_SHELLS + 1], s_smax[4], s_kcore[4], s_ksure[4];
     __shared__ float s_rcutsq[64], s_rinnersq[64], s_rcw[64], s_rlistsq[64];
     __shared__ uint32_t s_wide, s_bad, s_ncells, s_nmc, s_cmax;
 
@@ -219,6 +220,8 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
     if (tid < 4)
         {
         s_smax[tid] = 0;
+        s_kcore[tid] = 0;
+        s_ksure[tid] = 0xffffffffu;
         for (uint32_t sh = 0; sh <= PLAN_SHELLS; ++sh)
             s_kend[tid][sh] = 0;
         }
@@ -362,11 +365,11 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
             }
         return;
         }
-    // a raw entry: candidate number | class. 4 bits of class (core, near, 8 shells) when 12 bits hold the
-    // candidate number; else 3 (shells 5, 6, 7 are filed under 5 -- conservative, a shell is a lower bound)
+    // a raw entry: candidate number | class. 4 bits of class (core, sure, near, 8 shells) when 12 bits hold the
+    // candidate number; else 3 (shells 4 .. 7 are filed under 4 -- conservative, a shell is a lower bound)
     const uint32_t cbits = (NC <= 4096u) ? 4u : 3u;
     const uint32_t cmask = (1u << cbits) - 1u;
-    const float fmax_shell = (cbits == 4u) ? (float)(PLAN_SHELLS - 1u) : 5.f;
+    const float fmax_shell = (cbits == 4u) ? (float)(PLAN_SHELLS - 1u) : 4.f;
     // Acceptance test in single precision: r^2 <= r_list^2 (1 + 1e-5) + e, where e bounds what rounding the
     // staged coordinates (|coordinate| <= cmax: the members' extent + two cells) to FP32 can do to r^2:
     // 2 sqrt(3) r cmax 2^-23 = 4.2e-7 r cmax; taken as 1e-6 r_list cmax. A superset of the exact list, never less.
@@ -422,10 +425,24 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
         // r^2 -> class, at the lower edge of each bin (classes grow with r: never too high a class)
         const float rcsq_m = (float)a.rcutsq[0] * 1.0001f, rin = a.rinnersq ? (float)a.rinnersq[0] : 0.f;
         const float rcw = sqrtf(fmaxf((float)a.rcutsq[0], 0.f)) * shell_winv;
+        // class sure: certainly closer than r_cut - r_buff (r_buff = PLAN_SHELLS shell widths): the UPPER edge of the bin has
+        // to clear the radius, which itself is taken 2e-4 short (the single-precision separation is good to ~2e-6)
+        const float r_sure = (shell_w > 0.f) ? sqrtf(fmaxf((float)a.rcutsq[0], 0.f)) - (float)PLAN_SHELLS * shell_w - 2e-4f : 0.f;
+        const float sure_sq = r_sure > 0.f ? r_sure * r_sure : 0.f;
         for (uint32_t t = tid; t < PC_CTAB; t += PC_THREADS)
             {
             const float lo = (float)t * (rl1 * (1.0f / PC_CTAB)) * 0.999999f;
-            s_ctab[t] = (unsigned char)pair_class(lo, rcsq_m, rin, rcw, rscale, fmax_shell);
+            const float hi = (float)(t + 1u) * (rl1 * (1.0f / PC_CTAB)) * 1.000001f;
+            uint32_t cls = pair_class(lo, rcsq_m, rin, rcw, rscale, fmax_shell);
+            if (cls == PLAN_CLS_NEAR && hi < sure_sq)
+                cls = PLAN_CLS_SURE;
+            s_ctab[t] = (unsigned char)cls;
+            }
+        if (blockIdx.x == 0 && tid == 0)
+            {
+            // what the force kernel may rely on (margins for the single-precision test included)
+            a.flags[0] = (uint32_t)__float_as_int(r_sure > 0.f ? r_sure + 1e-4f : 0.f);
+            a.flags[7] = (uint32_t)__float_as_int(rin > 0.f ? sqrtf(rin) - 1e-4f : 0.f);
             }
         }
     // which member cell is mine
@@ -610,7 +627,7 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
     if (a.perm)
         {
         uint32_t* s_key = &s_runs[0][0]; // (the run table is not needed any more)
-        const uint32_t nin = member ? min((uint32_t)s_cur[tid] + (uint32_t)s_cur[PC_THREADS + tid], 1023u) : 0u;
+        const uint32_t nin = member ? min((uint32_t)s_cur[tid] + (uint32_t)s_cur[PC_THREADS + tid] + (uint32_t)s_cur[2 * PC_THREADS + tid], 1023u) : 0u;
         const uint32_t key = ((1023u - nin) << 8) | tid;
         s_key[tid] = key;
         __syncthreads();
@@ -696,8 +713,12 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
         const uint32_t v = s_cur[c * PC_THREADS + tid];
         s_cur[c * PC_THREADS + tid] = (uint16_t)before;
         before += v;
-        if (c >= 1u && member)
-            atomicMax(&s_kend[pw][c - 1u], (before + 7u) / 8u); // [0]: through "near", [1 + s]: through shell s
+        if (c >= PLAN_CLS_NEAR && member)
+            atomicMax(&s_kend[pw][c - PLAN_CLS_NEAR], (before + 7u) / 8u); // [0]: through "near", [1 + s]: through shell s
+        if (c == PLAN_CLS_CORE && member)
+            atomicMax(&s_kcore[pw], (before + 7u) / 8u);
+        if (c == PLAN_CLS_SURE && member)
+            atomicMin(&s_ksure[pw], before / 8u);
         }
     __syncthreads();
 #ifdef AZP_PLAN_CELLS_PROFILE
@@ -736,6 +757,8 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
         a.slice_head[slice] = (uint64_t)slice * Kcap;
         for (uint32_t sh = 0; sh <= PLAN_SHELLS; ++sh)
             a.slice_Kend[(PLAN_SHELLS + 1) * slice + sh] = s_kend[wave][sh];
+        a.slice_Kphase[slice] = s_kcore[wave];
+        a.slice_Kphase[a.n_tiles * 4u + slice] = (s_ksure[wave] == 0xffffffffu) ? 0u : s_ksure[wave]; // (a slice without a member)
         }
     }
 
@@ -791,6 +814,7 @@ int plan_build_from_cells(PairPlan& p, const azp_nlist_args& c, const azp_pair_a
     AZP_HIP_TRY(ensure_buf(p.d_slice_K, p.cap_slices, p.n_slices));
     AZP_HIP_TRY(ensure_buf(p.d_slice_Kend, p.cap_kend, (PLAN_SHELLS + 1) * (size_t)p.n_slices));
     AZP_HIP_TRY(ensure_buf(p.d_slice_head, cap_heads_s, p.n_slices));
+    AZP_HIP_TRY(ensure_buf(p.d_slice_Kphase, p.cap_kphase, 2 * (size_t)p.n_slices));
     size_t cap_flags = p.d_flags ? 8 : 0;
     AZP_HIP_TRY(ensure_buf(p.d_flags, cap_flags, 8));
     p.total_chunks = (uint64_t)p.n_slices * (row_cap / 8u);
@@ -817,6 +841,7 @@ int plan_build_from_cells(PairPlan& p, const azp_nlist_args& c, const azp_pair_a
     k.tile_head = p.d_tile_head;
     k.slice_K = p.d_slice_K;
     k.slice_Kend = p.d_slice_Kend;
+    k.slice_Kphase = p.d_slice_Kphase;
     k.slice_head = p.d_slice_head;
     k.cnl = p.d_cnl;
     k.flags = p.d_flags;
@@ -883,6 +908,10 @@ int plan_build_from_cells(PairPlan& p, const azp_nlist_args& c, const azp_pair_a
         float fm;
         __builtin_memcpy(&fm, &h_flags[3], sizeof(fm));
         p.shell_width = fm;
+        __builtin_memcpy(&p.sure_r, &h_flags[0], sizeof(float));
+        __builtin_memcpy(&p.core_r, &h_flags[7], sizeof(float));
+        if (c.ntypes != 1)
+            p.sure_r = p.core_r = 0.f; // (the phases serve the one-type split form of an evaluator only)
         }
     p.cap = plan_cap_for(p.max_stage);
     // identity of "the list" for the planned entry points: the plan's own raw rows and slice heads

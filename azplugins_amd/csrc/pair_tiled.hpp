@@ -20,6 +20,9 @@
 // rounding (the periodic shift is applied to r_j instead of to r_i - r_j).
 #pragma once
 
+#include <cstdlib>
+#include <type_traits>
+
 #include "pair_kernel.hpp"
 #include "pair_plan.hpp"
 
@@ -49,6 +52,15 @@ struct TiledKArgs
     const uint64_t* slice_head;
     const uint4* cnl;
     const uint8_t* perm;         // balanced plans (one lane per particle): lane -> member of the tile; NULL = identity
+    // Row phases (evaluators with a split form, one type pair): per slice the chunk count that covers every
+    // entry of class "core" [0] and the chunk count up to which every lane holds only entries of the classes
+    // core / sure [1] (pair_plan.hpp). With a displacement bound from the caller the chunks beyond [0] cannot
+    // hold a pair inside the evaluator's core, and the chunks [0] .. [1] hold only pairs that are certainly
+    // inside the cutoff: their tests are dropped (decided per wave from the bound and the radii below; exact).
+    const uint32_t* slice_Kcore;  // per slice; NULL: no phases
+    const uint32_t* slice_Ksure;
+    double bound;                 // the caller's displacement bound, < 0: unknown
+    float core_r, sure_r;         // class radii at build time, margins included; 0: class not built
     };
 
 // Stride (in slots) between the x, y and z arrays in LDS. With a stride of CAP the compiler
@@ -108,7 +120,11 @@ template<int CAP, int H> __device__ __forceinline__ void tile_gather(TileBatch& 
 // are formed first; if no lane of the wave has any of them inside the (largest)
 // cutoff, the evaluator work is skipped -- exact, and the common case at the far
 // end of the near-first ordered rows.
-template<class E, int CAP, bool VIRIAL, bool SINGLE, bool XPLOR, bool WRAP>
+// MODE (split evaluators only; everything else runs MODE 0): 0 = every test (pairs may be in the evaluator's
+// core, in its tail, or out of range), 1 = "sure": every pair of the batch is inside the cutoff and outside the
+// core -- no test at all, 2 = "tail": no pair is inside the core; cutoff test and the skip of batches without a
+// pair in range as in mode 0.
+template<class E, int CAP, bool VIRIAL, bool SINGLE, bool XPLOR, bool WRAP, int MODE = 0>
 __device__ __forceinline__ void tile_compute(const TileBatch& b, const TiledKArgs& a, const char* bt,
                                              const typename E::Coeff* __restrict__ s_coeff,
                                              const double* __restrict__ s_ronsq, const typename E::Coeff& c0, double ronsq0,
@@ -130,13 +146,14 @@ __device__ __forceinline__ void tile_compute(const TileBatch& b, const TiledKArg
         if (WRAP)
             rsq[e] = (b.off[e] == 0) ? 1.0e60 : rsq[e]; // the minimum image would fold the padding slot back into the box
                                                         // (1e60: out of range, and a product of four stays finite for rcp4)
-        any_in = any_in || (rsq[e] < rcutsq_max);
+        if (MODE != 1)
+            any_in = any_in || (rsq[e] < rcutsq_max);
         }
 #if defined(AZP_ABLATE) && (AZP_ABLATE == 3)
     fx += rsq[0] + rsq[1] + rsq[2] + rsq[3]; // ablation 3: gathers + separations only
     return;
 #endif
-    if (!__any(any_in))
+    if (MODE != 1 && !__any(any_in))
         return;
 #ifdef AZP_TILE_LANE_MASK
     // experiment: lanes without a pair in range in this batch sit the evaluator out (EXEC
@@ -166,10 +183,20 @@ __device__ __forceinline__ void tile_compute(const TileBatch& b, const TiledKArg
         // branches only produce fd[]; the accumulation below is shared, so the force
         // accumulators are not live-out of either branch (no register copies at the join).
         bool any_core = false;
+        if (MODE == 0)
+            {
 #pragma unroll
-        for (int e = 0; e < NB; ++e)
-            any_core = any_core || E::in_core(c0, rsq[e]);
-        if (!__any(any_core))
+            for (int e = 0; e < NB; ++e)
+                any_core = any_core || E::in_core(c0, rsq[e]);
+            }
+        if (MODE == 1)
+            {
+#pragma unroll
+            for (int e = 0; e < NB; ++e)
+                E::eval_split_sure(c0, x[e], fd[e], es[0], es[1]);
+            n_in += NB; // every pair of the batch is in range (finish_split ignores the count when the shift is zero)
+            }
+        else if (MODE == 2 || !__any(any_core))
             {
             const bool count_in = c0.tail_add != 0.0;
 #pragma unroll
@@ -232,7 +259,8 @@ template<class E, int TPP, int CAP, bool VIRIAL, bool SINGLE, bool XPLOR, bool W
 __device__ __forceinline__ void tiled_loop(const TiledKArgs& a, const char* bx, const char* bt,
                                            const typename E::Coeff* __restrict__ s_coeff,
                                            const double* __restrict__ s_ronsq, const typename E::Coeff& c0, double ronsq0,
-                                           double rcutsq_max, const char* __restrict__ slice_base, uint32_t lane_off, uint32_t K, double3 pi,
+                                           double rcutsq_max, const char* __restrict__ slice_base, uint32_t lane_off, uint32_t K,
+                                           uint32_t K1, uint32_t K2, double3 pi,
                                            int typei, double& fx, double& fy, double& fz, double& pe, double (&v)[6], uint32_t& n_core,
                                            uint32_t& n_in, double (&es)[2])
     {
@@ -247,23 +275,35 @@ __device__ __forceinline__ void tiled_loop(const TiledKArgs& a, const char* bx, 
     uint4 un = (K > 1) ? chunk_at(1) : u;
     TileBatch A, B;
     tile_gather<CAP, 0>(A, u, bx);
-    for (uint32_t kk = 0; kk < K; ++kk)
+    uint32_t kk = 0;
+    // the three phases of a row (K1 = K2 = K: one phase, every test) share the pipeline state
+    auto run = [&](auto mode, const uint32_t kend)
         {
-        // indices two chunks ahead (consumed 1.5 iterations from now: one iteration
-        // does not always cover an HBM round trip); past the end the last chunk is
-        // reloaded (an unconditional 16-byte load: a predicated one is split into
-        // four 4-byte loads)
-        const uint4 un2 = chunk_at((kk + 2 < K) ? kk + 2 : K - 1);
-        tile_gather<CAP, 1>(B, u, bx);
-        __builtin_amdgcn_sched_barrier(0);
-        tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(A, a, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, pi, typei, fx, fy, fz, pe, v, n_core, n_in, es);
-        __builtin_amdgcn_sched_barrier(0);
-        tile_gather<CAP, 0>(A, un, bx); // when kk + 1 == K: gathered, never used
-        __builtin_amdgcn_sched_barrier(0);
-        tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP>(B, a, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, pi, typei, fx, fy, fz, pe, v, n_core, n_in, es);
-        __builtin_amdgcn_sched_barrier(0);
-        u = un;
-        un = un2;
+        constexpr int MODE = decltype(mode)::value;
+        for (; kk < kend; ++kk)
+            {
+            // indices two chunks ahead (consumed 1.5 iterations from now: one iteration
+            // does not always cover an HBM round trip); past the end the last chunk is
+            // reloaded (an unconditional 16-byte load: a predicated one is split into
+            // four 4-byte loads)
+            const uint4 un2 = chunk_at((kk + 2 < K) ? kk + 2 : K - 1);
+            tile_gather<CAP, 1>(B, u, bx);
+            __builtin_amdgcn_sched_barrier(0);
+            tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP, MODE>(A, a, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, pi, typei, fx, fy, fz, pe, v, n_core, n_in, es);
+            __builtin_amdgcn_sched_barrier(0);
+            tile_gather<CAP, 0>(A, un, bx); // when kk + 1 == K: gathered, never used
+            __builtin_amdgcn_sched_barrier(0);
+            tile_compute<E, CAP, VIRIAL, SINGLE, XPLOR, WRAP, MODE>(B, a, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, pi, typei, fx, fy, fz, pe, v, n_core, n_in, es);
+            __builtin_amdgcn_sched_barrier(0);
+            u = un;
+            un = un2;
+            }
+        };
+    run(std::integral_constant<int, 0>(), K1);
+    if constexpr (SINGLE && !XPLOR && E::kSplitEnergy)
+        {
+        run(std::integral_constant<int, 1>(), K2);
+        run(std::integral_constant<int, 2>(), K);
         }
 #else
     // whole-chunk batches: chunk k+1's 24 gathers fly while chunk k is evaluated
@@ -484,11 +524,31 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
     double es[2] = {0.0, 0.0}; // tail-path energy sums (EvalPLJ::eval_split_tail)
     const char* bx = reinterpret_cast<const char*>(s_x);
     const char* bt = reinterpret_cast<const char*>(s_t);
+    // row phases: [0, K1) every test, [K1, K2) no test, [K2, K) no core test (see TiledKArgs)
+    uint32_t K1 = K, K2 = K;
+    if constexpr (SINGLE && !XPLOR && E::kSplitEnergy)
+        {
+        if (a.slice_Kcore && a.bound >= 0.0 && a.core_r > 0.f)
+            {
+            const double reach = 2.0 * a.bound;
+            const bool core_ok = E::core_radius(c0) + reach <= (double)a.core_r; // false for NaN (no interaction: c0.rcutsq < 0)
+            const bool sure_ok = core_ok && a.sure_r > 0.f && (double)a.sure_r + reach <= sqrt(c0.rcutsq);
+            if (core_ok)
+                {
+                K1 = to_uniform(min(a.slice_Kcore[slice], K));
+                K2 = sure_ok ? to_uniform(min(max(a.slice_Ksure[slice], K1), K)) : K1;
+                }
+            }
+        }
+#ifdef AZP_DEBUG_PHASES
+    if (tile == 7 && lane == 0)
+        printf("tile %u wave %u: K1 %u K2 %u K %u bound %g core_r %g sure_r %g n_shells %u wide %d\n", tile, wave, K1, K2, K, a.bound, (double)a.core_r, (double)a.sure_r, a.n_shells, (int)wide);
+#endif
     if (wide)
-        tiled_loop<E, TPP, CAP, VIRIAL, SINGLE, XPLOR, true>(a, bx, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, slice_base, lane_off, K, pi,
+        tiled_loop<E, TPP, CAP, VIRIAL, SINGLE, XPLOR, true>(a, bx, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, slice_base, lane_off, K, K1, K2, pi,
                                                             typei, fx, fy, fz, pe, v, n_core, n_in, es);
     else
-        tiled_loop<E, TPP, CAP, VIRIAL, SINGLE, XPLOR, false>(a, bx, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, slice_base, lane_off, K, pi,
+        tiled_loop<E, TPP, CAP, VIRIAL, SINGLE, XPLOR, false>(a, bx, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, slice_base, lane_off, K, K1, K2, pi,
                                                              typei, fx, fy, fz, pe, v, n_core, n_in, es);
     if constexpr (SINGLE && !XPLOR && E::kSplitEnergy)
         pe = E::finish_split(c0, pe, es[0], es[1], n_core, n_in);
@@ -540,6 +600,13 @@ int launch_tiled_instance2(const PairPlan& plan, const azp_pair_args& args, cons
     k.slice_K = plan.d_slice_K;
     k.slice_Kend = plan.d_slice_Kend;
     k.n_shells = plan_shells_for(plan, args);
+    // (AZP_ROW_PHASES=0 in the environment: every chunk takes every test -- A/B measurements)
+    static const bool phases = []() { const char* e = std::getenv("AZP_ROW_PHASES"); return !(e && e[0] == '0'); }();
+    k.slice_Kcore = phases ? plan.d_slice_Kphase : nullptr;
+    k.slice_Ksure = (phases && plan.d_slice_Kphase) ? plan.d_slice_Kphase + plan.n_slices : nullptr;
+    k.bound = (args.has_displacement_bound && args.displacement_bound >= 0.0) ? args.displacement_bound : -1.0;
+    k.core_r = plan.core_r;
+    k.sure_r = plan.sure_r;
     k.slice_head = plan.d_slice_head;
     k.cnl = plan.d_cnl;
     // sub-range launches are rounded outwards to whole tiles (a tile computed by

@@ -248,6 +248,9 @@ int launch_xtiled_instance(const PairPlan& plan, const azp_pair_args& args, cons
     k.slice_K = plan.d_slice_K;
     k.slice_Kend = plan.d_slice_Kend;
     k.n_shells = plan_shells_for(plan, args);
+    k.slice_Kcore = k.slice_Ksure = nullptr; // (row phases: pair_tiled.hpp only)
+    k.bound = -1.0;
+    k.core_r = k.sure_r = 0.f;
     k.slice_head = plan.d_slice_head;
     k.cnl = plan.d_cnl;
     const uint32_t t0 = k.p.first / 256u, t1 = (k.p.end + 255u) / 256u;

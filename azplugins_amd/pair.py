@@ -407,7 +407,9 @@ class PerturbedLennardJones(Pair):
     def _inner_radius(self, d):
         # the WCA core (r < 2^(1/6) sigma), plus the distance a pair can close before
         # the next neighbor-list rebuild
-        return 2.0 ** (1.0 / 6.0) * d["sigma"] + self.nlist.buffer
+        # (+ 1e-3: the tile kernel drops its core test beyond the first chunks of a row only while
+        # r_wca + 2 x displacement bound clears this radius by the plan's single-precision margin)
+        return 2.0 ** (1.0 / 6.0) * d["sigma"] + self.nlist.buffer + 1e-3
 
 
 class DPDGeneralWeight(Pair):

@@ -401,6 +401,8 @@ def main():
         by_step.append(dict(step=k, displacement_bound=bounds[k], bound_over_half_buffer=bounds[k] / (0.5 * r_buff), kernel_ms=timed()))
     side = {}
     plan_info = pot.plan_info  # of the plan the timed region ran on (the side figures below recompile it)
+    if plan_info and plan_info.get("valid"):
+        plan_info["mean_chunks_core_sure_row"] = pot._plan.phase_chunks()
     if n_states > 1 and not args.no_side_figures:
         # the same K launches, switching to the next cycle step at every launch (cold positions)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

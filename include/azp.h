@@ -224,6 +224,9 @@ typedef struct azp_pair_plan_info
                                     entry points (the plan is its own list; there is no u32 list) */
     int32_t balanced;            /* 1: rows handed to the lanes in the order of their in-range lengths
                                     (azp_pair_plan_set_balance) */
+    float core_radius;           /* row phases (one particle type): entries outside row class "core" were at least this
+                                    far apart when the plan was built; 0: no such class */
+    float sure_radius;           /* ... entries of row class "sure" at most this far apart; 0: no such class */
     int32_t _pad;
     } azp_pair_plan_info;
 
@@ -247,6 +250,10 @@ int azp_pair_plan_tile_stage(const azp_pair_plan* plan, uint32_t* out, uint32_t 
  * live for more than ~50 force calls; callers that rebuild more often turn it off. */
 int azp_pair_plan_set_bank_order(azp_pair_plan* plan, int enabled);
 int azp_pair_plan_query(const azp_pair_plan* plan, azp_pair_plan_info* info);
+/* Diagnostics (copies from the device, synchronises): the row phases of the last build as means over the slices --
+ * out[0] chunks that cover the core entries, out[1] chunks up to the end of the all-sure part of the rows, out[2]
+ * chunks of the whole rows. */
+int azp_pair_plan_phase_chunks(const azp_pair_plan* plan, float out[3]);
 
 /* The plan cache behind azp_pair_forces_* (diagnostics and tests). */
 typedef struct azp_auto_plan_stats
