@@ -51,6 +51,8 @@ class PairArgs(C.Structure):
         ("has_displacement_bound", C.c_uint32),
         ("_pad3", C.c_uint32),
         ("displacement_bound", C.c_double),
+        ("d_displacement", C.c_void_p),
+        ("displacement_bound_extra", C.c_double),
     ]
 
 
@@ -227,6 +229,7 @@ SYMBOLS = {
     "azp_pair_plan_tile_stage": (C.c_int, [_VP, C.POINTER(C.c_uint32), C.c_uint32]),
     "azp_pair_plan_query": (C.c_int, [_VP, C.POINTER(PlanInfo)]),
     "azp_pair_plan_phase_chunks": (C.c_int, [_VP, C.POINTER(C.c_float)]),
+    "azp_tuning_set": (C.c_int, [C.c_int, C.c_int]),
     "azp_pair_auto_plan_get_stats": (None, [C.POINTER(AutoPlanStats)]),
     "azp_pair_auto_plan_clear": (None, []),
     "azp_pair_forces_planned_perturbed_lennard_jones": (C.c_int, [_VP, C.POINTER(PairArgs), _VP, _VP]),
@@ -249,6 +252,7 @@ SYMBOLS = {
     "azp_halo_pack_fields": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(HaloField), _VP, _VP, C.c_uint32, _VP]),
     "azp_halo_unpack_fields": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(HaloField), _VP, C.c_uint32, _VP]),
     "azp_nlist_distance_check": (C.c_int, [C.c_uint32, _VP, _VP, C.POINTER(Box), _D, _VP, _VP, _VP]),
+    "azp_nlist_displacements": (C.c_int, [C.c_uint32, _VP, _VP, C.POINTER(Box), _D, _VP, _VP, _VP, _VP]),
     "azp_external_planar_harmonic_barrier": (C.c_int, [C.POINTER(BarrierArgs), _VP]),
     "azp_external_spherical_harmonic_barrier": (C.c_int, [C.POINTER(BarrierArgs), _VP]),
     "azp_planar_barrier_valid": (C.c_int, [_D, C.POINTER(Box)]),

@@ -1,6 +1,7 @@
 // azp_host.cpp -- host-only parts of the C ABI: parameter-struct construction
 // and inspection (what the reference's pybind11::dict constructors and
 // asDict()/toPython() do), status strings, launch bookkeeping.
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 
@@ -132,10 +133,36 @@ void azp_last_launch(uint32_t* block_size, uint32_t* threads_per_particle, uint3
     if (lds_bytes) *lds_bytes = li.lds_bytes;
     }
 
+int azp_tuning_set(int key, int value)
+    {
+    int* slot = key == AZP_TUNE_ROW_PHASES ? &azp::tuning().row_phases : (key == AZP_TUNE_LOCAL_BOUND ? &azp::tuning().local_bound : nullptr);
+    if (!slot)
+        return -1;
+    const int old = *slot;
+    *slot = value ? 1 : 0;
+    return old;
+    }
+
 } // extern "C"
 
 namespace azp
 {
+Tuning& tuning()
+    {
+    static Tuning t = []()
+        {
+        Tuning v;
+        // off by default: measured on the north star (tools/ab_cycle.py) the phases issue 1 % fewer VALU
+        // instructions and run 1.5 % SLOWER -- the kernel is held by its LDS gathers, not by VALU issue
+        const char* e = std::getenv("AZP_ROW_PHASES");
+        v.row_phases = (e && e[0] == '1');
+        e = std::getenv("AZP_LOCAL_BOUND");
+        v.local_bound = !(e && e[0] == '0');
+        return v;
+        }();
+    return t;
+    }
+
 LaunchInfo& last_launch()
     {
     static thread_local LaunchInfo li = {0, 0, 0, 0};

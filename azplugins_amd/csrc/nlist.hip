@@ -304,7 +304,8 @@ template<bool FILL, bool MI> __global__ void __launch_bounds__(NL_THREADS) nlist
 
 __global__ void __launch_bounds__(256) distance_check_kernel(uint32_t n, const double* __restrict__ pos,
                                                              const double* __restrict__ pos0, BoxDev box, double max_dist_sq,
-                                                             uint32_t* __restrict__ flag, unsigned long long* __restrict__ max_bits)
+                                                             uint32_t* __restrict__ flag, unsigned long long* __restrict__ max_bits,
+                                                             float* __restrict__ disp)
     {
     // grid-stride over at most 512 workgroups, each ending in at most one atomic
     double dsq_max = 0.0;
@@ -313,7 +314,14 @@ __global__ void __launch_bounds__(256) distance_check_kernel(uint32_t n, const d
         const double3 p = load_scalar3_of4(pos, i), q = load_scalar3_of4(pos0, i);
         double dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
         min_image(box, dx, dy, dz);
-        dsq_max = fmax(dsq_max, dx * dx + dy * dy + dz * dz);
+        const double dsq = dx * dx + dy * dy + dz * dz;
+        dsq_max = fmax(dsq_max, dsq);
+        if (disp)
+            {
+            // an UPPER bound in single precision (the tile kernels take maxima of these); NaN -> +inf
+            const double d = sqrt(dsq) * (1.0 + 1e-15);
+            disp[i] = (d == d) ? __double2float_ru(d) : __int_as_float(0x7f800000);
+            }
         }
     for (int off = 32; off > 0; off >>= 1)
         dsq_max = fmax(dsq_max, __shfl_xor(dsq_max, off, 64));
@@ -445,6 +453,21 @@ extern "C" int azp_nlist_distance_check(uint32_t n, const double* d_pos, const d
         return AZP_SUCCESS;
     const uint32_t blocks = (n + 255u) / 256u;
     hipLaunchKernelGGL(distance_check_kernel, dim3(blocks < 512u ? blocks : 512u), dim3(256), 0, static_cast<hipStream_t>(stream), n, d_pos,
-                       d_pos_at_build, make_box_dev(*box), max_dist_sq, d_flag, d_max_dist_sq_bits);
+                       d_pos_at_build, make_box_dev(*box), max_dist_sq, d_flag, d_max_dist_sq_bits, (float*)nullptr);
+    return (int)hipGetLastError();
+    }
+
+extern "C" int azp_nlist_displacements(uint32_t n, const double* d_pos, const double* d_pos_at_build, const azp_box* box,
+                                       double max_dist_sq, uint32_t* d_flag, unsigned long long* d_max_dist_sq_bits,
+                                       float* d_displacement, void* stream)
+    {
+    using namespace azp;
+    if (!d_pos || !d_pos_at_build || !box || !d_flag || !d_displacement || !(max_dist_sq >= 0.0))
+        return AZP_ERROR_INVALID_ARGUMENT;
+    if (n == 0)
+        return AZP_SUCCESS;
+    const uint32_t blocks = (n + 255u) / 256u;
+    hipLaunchKernelGGL(distance_check_kernel, dim3(blocks < 512u ? blocks : 512u), dim3(256), 0, static_cast<hipStream_t>(stream), n, d_pos,
+                       d_pos_at_build, make_box_dev(*box), max_dist_sq, d_flag, d_max_dist_sq_bits, d_displacement);
     return (int)hipGetLastError();
     }

@@ -61,7 +61,38 @@ struct TiledKArgs
     const uint32_t* slice_Ksure;
     double bound;                 // the caller's displacement bound, < 0: unknown
     float core_r, sure_r;         // class radii at build time, margins included; 0: class not built
+    // Local displacement bound (azp_pair_args.d_displacement): per-particle upper bounds on the distance moved since the
+    // plan was built. A tile then walks the shells ITS members and staged neighbors can have crossed -- an entry of shell s
+    // was at least r_cut + s w away, and the two particles of a pair have closed in by at most the sum of their own
+    // displacements <= 2 x the largest one in the tile -- instead of the shells the fastest particle of the whole system
+    // dictates. bound_extra is added to every entry (a plan compiled later than the positions the displacements refer to).
+    const float* disp;            // n_max entries; NULL: the global bound above
+    double shell_w;               // shell width of the plan
+    double shell_winv;            // 1 / shell_w (0: no shells)
+    double bound_extra;
     };
+
+// wave-wide maximum of a non-negative float (all lanes get it)
+__device__ __forceinline__ float wave_max_nonneg(float v)
+    {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+    }
+
+// Shells a tile has to walk for the displacement bound b of its own particles (device form of plan_shells_for)
+__device__ __forceinline__ uint32_t tile_shells_for(double b, double shell_winv)
+    {
+    if (!(b >= 0.0))
+        return PLAN_SHELLS; // NaN
+    if (b == 0.0)
+        return 0u;
+    if (!(shell_winv > 0.0))
+        return PLAN_SHELLS;
+    const double n = ceil(2.0 * b * (1.0 + 1e-9) * shell_winv); // (1e-9 covers the rounded reciprocal)
+    return n >= (double)PLAN_SHELLS ? PLAN_SHELLS : (uint32_t)n;
+    }
 
 // Stride (in slots) between the x, y and z arrays in LDS. With a stride of CAP the compiler
 // fuses the x and y gathers of a pair into one ds_read2st64_b64, which runs at half the LDS
@@ -83,6 +114,19 @@ struct TileBatch
     double x[AZP_TILE_BATCH], y[AZP_TILE_BATCH], z[AZP_TILE_BATCH];
     uint32_t off[AZP_TILE_BATCH];
     };
+
+// the local-displacement fields of the kernel arguments (pair_tiled.hpp and xtiled.hpp launchers)
+inline void fill_local_bound(TiledKArgs& k, const PairPlan& plan, const azp_pair_args& args)
+    {
+    // per-particle displacements count only together with a (global) bound: has_displacement_bound says the caller
+    // tracks displacements since the plan build at all; displacement_bound_extra covers a plan built later than the
+    // reference positions of d_displacement
+    const bool local = args.d_displacement && args.has_displacement_bound && args.displacement_bound >= 0.0;
+    k.disp = (local && tuning().local_bound != 0) ? args.d_displacement : nullptr;
+    k.shell_w = plan.shell_width;
+    k.shell_winv = plan.shell_width > 0.0 ? 1.0 / plan.shell_width : 0.0;
+    k.bound_extra = args.displacement_bound_extra > 0.0 ? args.displacement_bound_extra : 0.0;
+    }
 
 // phase 1: issue the LDS gathers of a batch (half H of the chunk when NB = 4)
 template<int CAP, int H> __device__ __forceinline__ void tile_gather(TileBatch& b, const uint4& u, const char* bx)
@@ -412,6 +456,7 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
     // the staged image of a neighbor IS its minimum image for every member.
     const bool no_hint = !(a.p.r_list_max > 0.0);
     bool far_from_c = false;
+    float dmax = a.disp ? a.disp[active ? idx : first] : 0.f; // largest displacement among what this lane stages, and its own
     {
     constexpr int ROUNDS = (CAP + 255) / 256; // n_stage < CAP
     uint32_t sj[ROUNDS];
@@ -427,6 +472,13 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
 #endif
     double sxv[ROUNDS], syv[ROUNDS], szv[ROUNDS];
     int stv[ROUNDS];
+    if (a.disp)
+        {
+        // (lanes beyond the staged set read the reference particle's entry: a member of the tile anyway)
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r)
+            dmax = fmaxf(dmax, a.disp[sj[r]]);
+        }
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r)
         {
@@ -500,6 +552,13 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
     __builtin_amdgcn_s_waitcnt(0);
     tl_td = __builtin_amdgcn_s_memrealtime();
 #endif
+    __shared__ float s_dmax[4];
+    if (a.disp)
+        {
+        dmax = wave_max_nonneg(dmax);
+        if (lane == 0)
+            s_dmax[wave] = dmax;
+        }
     const bool wide = __syncthreads_or(lane_wide); // also publishes the staged tile
 #ifndef AZP_NO_STAGE_PRIO
     __builtin_amdgcn_s_setprio(0);
@@ -507,12 +566,23 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
 #ifdef AZP_TIMELINE
     const unsigned long long tl_t1 = __builtin_amdgcn_s_memrealtime();
 #endif
+    // the displacement bound of this tile and the shells it has to walk
+    double bound = a.bound;
+    uint32_t n_shells = a.n_shells;
+    if (a.disp)
+        {
+        const float d4 = fmaxf(fmaxf(s_dmax[0], s_dmax[1]), fmaxf(s_dmax[2], s_dmax[3]));
+        bound = to_uniform((double)d4 + a.bound_extra); // NaN / inf displacements: whole rows, every test
+        n_shells = tile_shells_for(bound, a.shell_winv);
+        if (!(bound >= 0.0) || !(bound < 1.0e300))
+            bound = -1.0;
+        }
 
     const uint32_t slice = tile * 4 + wave;
     // scalar trip count (the loop counter and the chunk address stay in SGPRs). With a
     // displacement bound from the caller the row ends early: entries that were at
     // least 2 x bound outside the cutoff when the plan was built cannot be in range.
-    const uint32_t K = to_uniform(a.n_shells >= PLAN_SHELLS ? a.slice_K[slice] : a.slice_Kend[(PLAN_SHELLS + 1) * slice + a.n_shells]);
+    const uint32_t K = to_uniform(n_shells >= PLAN_SHELLS ? a.slice_K[slice] : a.slice_Kend[(PLAN_SHELLS + 1) * slice + n_shells]);
     // wave-uniform slice base (SGPRs) + lane: the loads use scalar-base addressing
     const uint64_t slice_head = to_uniform(a.slice_head[slice]);
     const char* __restrict__ slice_base = reinterpret_cast<const char*>(a.cnl + slice_head * 64ull);
@@ -528,9 +598,9 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
     uint32_t K1 = K, K2 = K;
     if constexpr (SINGLE && !XPLOR && E::kSplitEnergy)
         {
-        if (a.slice_Kcore && a.bound >= 0.0 && a.core_r > 0.f)
+        if (a.slice_Kcore && bound >= 0.0 && a.core_r > 0.f)
             {
-            const double reach = 2.0 * a.bound;
+            const double reach = 2.0 * bound;
             const bool core_ok = E::core_radius(c0) + reach <= (double)a.core_r; // false for NaN (no interaction: c0.rcutsq < 0)
             const bool sure_ok = core_ok && a.sure_r > 0.f && (double)a.sure_r + reach <= sqrt(c0.rcutsq);
             if (core_ok)
@@ -542,7 +612,7 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
         }
 #ifdef AZP_DEBUG_PHASES
     if (tile == 7 && lane == 0)
-        printf("tile %u wave %u: K1 %u K2 %u K %u bound %g core_r %g sure_r %g n_shells %u wide %d\n", tile, wave, K1, K2, K, a.bound, (double)a.core_r, (double)a.sure_r, a.n_shells, (int)wide);
+        printf("tile %u wave %u: K1 %u K2 %u K %u bound %g (global %g) core_r %g sure_r %g n_shells %u (global %u) wide %d\n", tile, wave, K1, K2, K, bound, a.bound, (double)a.core_r, (double)a.sure_r, n_shells, a.n_shells, (int)wide);
 #endif
     if (wide)
         tiled_loop<E, TPP, CAP, VIRIAL, SINGLE, XPLOR, true>(a, bx, bt, s_coeff, s_ronsq, c0, ronsq0, rcutsq_max, slice_base, lane_off, K, K1, K2, pi,
@@ -600,13 +670,13 @@ int launch_tiled_instance2(const PairPlan& plan, const azp_pair_args& args, cons
     k.slice_K = plan.d_slice_K;
     k.slice_Kend = plan.d_slice_Kend;
     k.n_shells = plan_shells_for(plan, args);
-    // (AZP_ROW_PHASES=0 in the environment: every chunk takes every test -- A/B measurements)
-    static const bool phases = []() { const char* e = std::getenv("AZP_ROW_PHASES"); return !(e && e[0] == '0'); }();
+    const bool phases = tuning().row_phases != 0; // (azp_tuning_set: A/B measurements)
     k.slice_Kcore = phases ? plan.d_slice_Kphase : nullptr;
     k.slice_Ksure = (phases && plan.d_slice_Kphase) ? plan.d_slice_Kphase + plan.n_slices : nullptr;
     k.bound = (args.has_displacement_bound && args.displacement_bound >= 0.0) ? args.displacement_bound : -1.0;
     k.core_r = plan.core_r;
     k.sure_r = plan.sure_r;
+    fill_local_bound(k, plan, args);
     k.slice_head = plan.d_slice_head;
     k.cnl = plan.d_cnl;
     // sub-range launches are rounded outwards to whole tiles (a tile computed by

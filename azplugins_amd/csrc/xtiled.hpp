@@ -77,6 +77,7 @@ __global__ void __launch_bounds__(256, X::kMinWaves) xtiled_kernel(const TiledKA
     const bool active = idx < a.p.end;
     const bool no_hint = !(a.p.r_list_max > 0.0);
     bool lane_wide = a.p.box.triclinic;
+    float dmax = a.disp ? a.disp[active ? idx : first] : 0.f; // local displacement bound (pair_tiled.hpp)
     // all loads of the staging are issued before the first result is used: the index loads of
     // every round, then every position / payload load (two dependent round trips per tile)
     __builtin_amdgcn_s_setprio(3); // a new tile shares its SIMDs with waves deep in the pair loop
@@ -92,6 +93,12 @@ __global__ void __launch_bounds__(256, X::kMinWaves) xtiled_kernel(const TiledKA
     double4 pj[ROUNDS];
     double ext[ROUNDS][NE];
     uint32_t tagj[ROUNDS];
+    if (a.disp)
+        {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r)
+            dmax = fmaxf(dmax, a.disp[sj[r]]);
+        }
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r)
         {
@@ -147,11 +154,21 @@ __global__ void __launch_bounds__(256, X::kMinWaves) xtiled_kernel(const TiledKA
         pi = make_double3(px, py, pz);
         typei = type_from_w(p.w);
         }
+    __shared__ float s_dmax[4];
+    if (a.disp)
+        {
+        dmax = wave_max_nonneg(dmax);
+        if (lane == 0)
+            s_dmax[wave] = dmax;
+        }
     const bool wide = __syncthreads_or(lane_wide); // also publishes the staged tile
     __builtin_amdgcn_s_setprio(0);
+    uint32_t n_shells = a.n_shells;
+    if (a.disp)
+        n_shells = tile_shells_for(to_uniform((double)fmaxf(fmaxf(s_dmax[0], s_dmax[1]), fmaxf(s_dmax[2], s_dmax[3])) + a.bound_extra), a.shell_winv);
 
     const uint32_t slice = tile * 4 + wave;
-    const uint32_t K = to_uniform(a.n_shells >= PLAN_SHELLS ? a.slice_K[slice] : a.slice_Kend[(PLAN_SHELLS + 1) * slice + a.n_shells]);
+    const uint32_t K = to_uniform(n_shells >= PLAN_SHELLS ? a.slice_K[slice] : a.slice_Kend[(PLAN_SHELLS + 1) * slice + n_shells]);
     const uint64_t slice_head = to_uniform(a.slice_head[slice]);
     const uint4* __restrict__ rows = a.cnl + slice_head * 64ull + lane;
 
@@ -251,6 +268,7 @@ int launch_xtiled_instance(const PairPlan& plan, const azp_pair_args& args, cons
     k.slice_Kcore = k.slice_Ksure = nullptr; // (row phases: pair_tiled.hpp only)
     k.bound = -1.0;
     k.core_r = k.sure_r = 0.f;
+    fill_local_bound(k, plan, args);
     k.slice_head = plan.d_slice_head;
     k.cnl = plan.d_cnl;
     const uint32_t t0 = k.p.first / 256u, t1 = (k.p.end + 255u) / 256u;

@@ -158,13 +158,18 @@ class Cell(NeighborList):
         self._flag_i += 1
         box = state.box.to_c()
         stream = _lib.raw_stream(state.device)
-        _lib.check(_lib.lib().azp_nlist_distance_check(state.n_max, state.pos.data_ptr(), self._pos_at_build.data_ptr(),
-                                                       C.byref(box), (0.5 * self.buffer) ** 2, row.data_ptr(),
-                                                       row.data_ptr() + 8, stream),
-                   "azp_nlist_distance_check")
+        # every particle's own displacement next to the maximum: the tile kernels take the maximum over what a
+        # tile stages (azp_pair_args.d_displacement) instead of the global one
+        if getattr(self, "_disp_arr", None) is None or self._disp_arr.shape[0] != state.n_max or self._disp_arr.device != state.pos.device:
+            self._disp_arr = torch.zeros(state.n_max, dtype=torch.float32, device=state.pos.device)
+        _lib.check(_lib.lib().azp_nlist_displacements(state.n_max, state.pos.data_ptr(), self._pos_at_build.data_ptr(),
+                                                      C.byref(box), (0.5 * self.buffer) ** 2, row.data_ptr(),
+                                                      row.data_ptr() + 8, self._disp_arr.data_ptr(), stream),
+                   "azp_nlist_displacements")
         flag, bits = row.tolist()
         self._disp = float(np.sqrt(np.array([bits], dtype=np.int64).view(np.float64)[0]))
         self._disp_generation = state.position_generation
+        self._disp_arr_generation = state.position_generation
         return bool(flag)
 
     def displacement_bound(self, state):
@@ -174,14 +179,26 @@ class Cell(NeighborList):
             return self._disp
         return None
 
-    def assume_displacement(self, state, bound):
+    def displacements(self, state):
+        """Per-particle displacements since the list was built (float32 device tensor of n_max upper
+        bounds), if known for the current positions (else None)."""
+        if getattr(self, "_disp_arr_generation", None) == state.position_generation and getattr(self, "_disp_arr", None) is not None:
+            return self._disp_arr
+        return None
+
+    def assume_displacement(self, state, bound, per_particle=None):
         """Benchmark / replay hook: the caller vouches that the current positions are within
         ``bound`` of the positions the list was built for (e.g. a stored snapshot of a run whose
-        distance check returned exactly that), so no distance check runs for them."""
+        distance check returned exactly that), so no distance check runs for them.
+        ``per_particle``: that check's per-particle displacements (a clone of ``displacements()``)."""
         if not self.built:
             raise _lib.AzpError("assume_displacement: the list has not been built")
         self._built_generation = state.position_generation
         self._disp, self._disp_generation = float(bound), state.position_generation
+        if per_particle is not None:
+            self._disp_arr, self._disp_arr_generation = per_particle, state.position_generation
+        else:
+            self._disp_arr_generation = None
 
     def _build(self, state):
         import torch

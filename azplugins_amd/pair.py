@@ -43,6 +43,9 @@ class Pair(Force):
         self.block_size = 0
         self.use_plan = True            # LDS-staged tile kernel when the neighbor list can be tiled
         self.use_displacement_bound = True  # let it stop rows early while particles have barely moved (exact)
+        # ... by the displacements of each tile's own particles instead of the global maximum: pays when a few
+        # particles move much farther than the rest; on a liquid in equilibrium it costs 1 %, so opt-in
+        self.use_local_displacement = False
         self.plan_bank_order = None     # None: bank-aware rows only for long-lived lists (below); True / False: always / never
         self.use_fused_plan = True      # sole consumer of its list: compile the plan straight from the binned particles
         self._plan_ids = None
@@ -221,6 +224,10 @@ class Pair(Force):
         d0 = getattr(self, "_plan_disp0", None)
         if bound is not None and d0 is not None and self.use_displacement_bound:
             a.has_displacement_bound, a.displacement_bound = 1, bound + d0
+            darr = nl.displacements(st) if (self.use_local_displacement and hasattr(nl, "displacements")) else None
+            if darr is not None and darr.shape[0] == st.n_max:
+                self._disp_keepalive = darr
+                a.d_displacement, a.displacement_bound_extra = darr.data_ptr(), d0
         rng = getattr(self, "_range", None)
         if rng is not None:
             a.range_first, a.range_count = int(rng[0]), int(rng[1])
@@ -278,6 +285,7 @@ class Pair(Force):
                 b = nl.displacement_bound(self._state)
                 known = b is not None and self.use_displacement_bound
                 a.has_displacement_bound, a.displacement_bound = (1, b) if known else (0, 0.0)
+                a.displacement_bound_extra = 0.0
             else:
                 # particles not spatially sorted / a tile stages too much: the list-based path. A list
                 # whose tiles fail twice in a row (e.g. the thin boundary shells of a decomposed DPD
@@ -304,6 +312,7 @@ class Pair(Force):
             self._plan_disp0 = self.nlist.displacement_bound(self._state)
             # this launch sees exactly the positions the plan was built from
             a.has_displacement_bound, a.displacement_bound = (1 if self.use_displacement_bound else 0), 0.0
+            a.d_displacement = None  # (those refer to the positions the LIST was built from)
         self._calls_since_plan = getattr(self, "_calls_since_plan", 0) + 1
 
     def _plan_key(self):

@@ -214,6 +214,9 @@ def main():
     ap.add_argument("--balance", type=int, default=-1,
                     help="1 / 0: rows of a tile to its lanes by in-range length (balanced plans) on / off; default: the class's own choice")
     ap.add_argument("--sort-rows", action="store_true", help="experiment: sort every neighbor row by index before planning")
+    ap.add_argument("--local-bound", action="store_true",
+                    help="also give the kernel the per-particle displacements of the distance check (a tile then stops its rows by the "
+                         "displacements of its own particles; off by default: +1 %% on this workload, tools/ab_cycle.py)")
     ap.add_argument("--no-displacement-bound", action="store_true",
                     help="do not tell the planned kernel how far particles moved since the list was built (it then walks "
                          "whole rows, Verlet-buffer entries included)")
@@ -276,8 +279,10 @@ def main():
     # (args.static: the round-1 figure, the snapshot the list was built for, no particle moved)
     st = sim.state
     r_buff = cfg["r_buff"]
+    pot.use_local_displacement = bool(args.local_bound)
     if args.static or args.displace > 0.0 or args.sort_rows:
         snaps, bounds = [st.pos], [nl.displacement_bound(st)]
+        disps = [nl.displacements(st)]
     else:
         x0 = st.pos.clone()
         snaps = record_md_cycle(sim, nl, args.kT, seed=7)
@@ -289,19 +294,22 @@ def main():
         nl.compute(st, force=True)
         pot.compute(0)
         builds = nl.num_builds
-        bounds = []
+        bounds, disps = [], []
         for x in snaps:  # the distance check of every step, as the MD run made it
             st.pos = x
             st.position_generation += 1
             pot.compute(0)
             assert nl.num_builds == builds, "a recorded step triggered a rebuild"
             bounds.append(nl.displacement_bound(st))
+            d = nl.displacements(st)
+            disps.append(d.clone() if d is not None else None)  # (step 0 runs no check: no array, global bound 0)
     n_states = len(snaps)
 
     def set_state(k):
         st.pos = snaps[k]
         st.position_generation += 1
-        nl.assume_displacement(st, bounds[k])  # known from the recorded run: no distance-check kernel in the timed loop
+        # known from the recorded run (the maximum and every particle's own): no distance-check kernel in the timed loop
+        nl.assume_displacement(st, bounds[k], per_particle=disps[k])
 
     # Timed order: the K steps walk through the cycle ONCE, steps // n_states consecutive launches on
     # each state (state of step k = k * n_states // K), so that every cycle step carries the same
@@ -485,6 +493,7 @@ def main():
             "kernel_ms_other_states": side,
             "plan_bank_order": bool(pot.plan_bank_order) if n_states > 1 else None,
             "displacement_bound_passed": bool(pot.use_displacement_bound),
+            "per_particle_displacements_passed": bool(pot.use_local_displacement),
             "launch": launch,
             "tile_plan": plan_info,
             "parallelism": "1 GPU",

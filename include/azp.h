@@ -168,6 +168,16 @@ typedef struct azp_pair_args
                                       larger: whole rows.
                                     HOOMD: max |x - x_at_last_nlist_update|, the quantity
                                     NeighborList::distanceCheck compares with r_buff / 2.    */
+    const float* d_displacement; /* optional (with has_displacement_bound != 0), read by the *_planned entry
+                                    points: n_max per-particle upper bounds on the distance each particle has moved
+                                    since the positions the plan's row classes refer to (azp_nlist_displacements
+                                    writes them next to the global maximum). A tile of the kernel then stops its rows
+                                    at the shells ITS OWN members and listed neighbors can have crossed (twice the
+                                    largest of their displacements) instead of what the fastest particle of the whole
+                                    system dictates. Exact; NULL = the global bound alone.  */
+    double displacement_bound_extra; /* added to every d_displacement entry: how far any particle had moved from those
+                                    reference positions when the plan was built (0 in the usual flow: plan and list are
+                                    built from the same positions) */
     } azp_pair_args;
 
 /* The five entry points below take what gpu_compute_pair_forces<E> takes and nothing
@@ -429,6 +439,11 @@ int azp_pair_plan_build_from_cells(azp_pair_plan* plan, const azp_nlist_args* ce
  * planned force kernels accept (azp_pair_args.displacement_bound). */
 int azp_nlist_distance_check(uint32_t n, const double* d_pos, const double* d_pos_at_build, const azp_box* box,
                              double max_dist_sq, uint32_t* d_flag, unsigned long long* d_max_dist_sq_bits, void* stream);
+/* The same check that also writes every particle's own displacement (single precision, rounded up) to
+ * d_displacement[0 .. n): the per-particle bounds azp_pair_args.d_displacement takes. */
+int azp_nlist_displacements(uint32_t n, const double* d_pos, const double* d_pos_at_build, const azp_box* box,
+                            double max_dist_sq, uint32_t* d_flag, unsigned long long* d_max_dist_sq_bits,
+                            float* d_displacement, void* stream);
 
 /* Sort keys of the particle sorter (the role of HOOMD's SFC sorter, which the tile plan relies
  * on): key of particle i = index of its cell along a blocked curve over a dims[0] x dims[1] x
@@ -544,6 +559,14 @@ const char* azp_status_string(int status);
 /* Resolved launch configuration of the last pair-force call on this thread
  * (for benchmarks / profiling reports). */
 void azp_last_launch(uint32_t* block_size, uint32_t* threads_per_particle, uint32_t* grid, uint32_t* lds_bytes);
+/* Process-wide switches of the tile kernels, for A/B measurements (results are identical either way):
+ * AZP_TUNE_ROW_PHASES (default 0: it measures 1.5 % slower on the north star although it issues fewer
+ * instructions): the test-free / core-test-free parts of a row (csrc/pair_tiled.hpp);
+ * AZP_TUNE_LOCAL_BOUND (default 1): azp_pair_args.d_displacement is used when given.
+ * Returns the previous value, or -1 for an unknown key. The environment variables AZP_ROW_PHASES=1 /
+ * AZP_LOCAL_BOUND=0 set the initial values. */
+enum { AZP_TUNE_ROW_PHASES = 1, AZP_TUNE_LOCAL_BOUND = 2 };
+int azp_tuning_set(int key, int value);
 
 #ifdef __cplusplus
 }

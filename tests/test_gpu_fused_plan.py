@@ -32,7 +32,7 @@ PLANNED = {
 
 
 def fused_forces(name, pos, box, params, r_cut, r_buff, ntypes=1, N=None, mode="none", r_on=0.0, virial=False, exclusions=None,
-                 row_capacity=0, moved=None, bound=None, prange=None, r_inner=None, balance=False):
+                 row_capacity=0, moved=None, bound=None, prange=None, r_inner=None, balance=False, disp=None):
     """Bin, compile the plan from the bins, run the planned kernel; returns (force[, virial], info)."""
     import torch
 
@@ -60,6 +60,9 @@ def fused_forces(name, pos, box, params, r_cut, r_buff, ntypes=1, N=None, mode="
         t["pos"].copy_(torch.from_numpy(np.ascontiguousarray(moved)).to("cuda:0"))
     if bound is not None:
         a.has_displacement_bound, a.displacement_bound = 1, float(bound)
+    if disp is not None:
+        t["disp"] = torch.from_numpy(np.ascontiguousarray(disp, dtype=np.float32)).to("cuda:0")
+        a.d_displacement = t["disp"].data_ptr()
     if prange is not None:
         a.range_first, a.range_count = prange
     p = H._dev(np.atleast_2d(params).astype(np.float64))
@@ -196,6 +199,41 @@ def test_fused_plan_after_particles_moved(oracle, frac):
         f_gpu, info = fused_forces(PLJ, pos0, (L,), params, r_cut, r_buff, mode="shift", moved=moved, bound=bound, r_inner=r_wca + r_buff)
         assert info["valid"] == 1
         assert_close(f_gpu, f_ref)
+
+
+@pytest.mark.parametrize("few", [0.002, 0.05, 1.0])
+def test_fused_plan_local_displacement_bound(oracle, few):
+    """Per-particle displacements (azp_pair_args.d_displacement): a fraction ``few`` of the particles moves by up to
+    0.99 r_buff / 2, the rest by a hundredth of that, so most tiles stop their rows many shells before what the global
+    bound dictates -- and the forces are still the oracle's on the moved positions with the old list. The inner radius
+    is the one azplugins_amd.pair passes (r_wca + r_buff + 1e-3: row phases active)."""
+    cfg = syn.config_plj_sc(20)
+    n = cfg["xyz"].shape[0]
+    L = cfg["L"]
+    pos0 = syn.pos4(cfg["xyz"])
+    box = oracle.make_box(L)
+    r_cut, r_buff = 3.0, 0.4
+    params = oracle.pack_pair_params(PLJ, cfg["params"])
+    nl = oracle.build_nlist(pos0, box, r_cut + r_buff)
+    tag = np.arange(n, dtype=np.uint64)
+    v = np.stack([syn.normal(91, tag, c) for c in range(3)], axis=1)
+    v /= np.linalg.norm(v, axis=1)[:, None]
+    fast = syn.u01(92, tag, 0) < few
+    length = np.where(fast, 0.99, 0.0099) * 0.5 * r_buff * syn.u01(93, tag, 1)
+    v *= length[:, None]
+    moved = syn.pos4(syn.wrap(cfg["xyz"] + v, L))
+    f_ref = oracle.pair_forces(PLJ, moved, box, nl, params, r_cut, 0.0, "shift", nthreads=8)
+    r_wca = 2.0 ** (1.0 / 6.0) * cfg["params"]["sigma"]
+    disp = np.nextafter(np.linalg.norm(v, axis=1).astype(np.float32) * np.float32(1.000001), np.float32(np.inf))
+    f_gpu, info = fused_forces(PLJ, pos0, (L,), params, r_cut, r_buff, mode="shift", moved=moved, bound=float(disp.max()), disp=disp,
+                               r_inner=r_wca + r_buff + 1e-3)
+    assert info["valid"] == 1 and info["core_radius"] > 0 and info["sure_radius"] > 0
+    assert_close(f_gpu, f_ref)
+    # the same launch with the global bound alone gives the same bits (both are exact evaluations of the same pairs
+    # in the same order; only the number of skipped out-of-range entries differs)
+    f_glob, _ = fused_forces(PLJ, pos0, (L,), params, r_cut, r_buff, mode="shift", moved=moved, bound=float(disp.max()),
+                             r_inner=r_wca + r_buff + 1e-3)
+    assert np.array_equal(f_gpu, f_glob)
 
 
 def test_fused_plan_row_capacity_protocol(oracle):
