@@ -52,6 +52,7 @@ class PairArgs(C.Structure):
         ("_pad3", C.c_uint32),
         ("displacement_bound", C.c_double),
         ("d_displacement", C.c_void_p),
+        ("list_generation", C.c_uint64),
         ("displacement_bound_extra", C.c_double),
     ]
 

@@ -8,6 +8,7 @@
 // quaternion (32 B) gathers; the patch director n = rotate(q, x^) of particle i
 // is computed once per particle, that of j once per pair. Outputs: force
 // (fx, fy, fz, e) and torque (tx, ty, tz, 0), both N x 4.
+#include "pair_auto.hpp"
 #include "xtiled.hpp"
 
 namespace azp
@@ -360,6 +361,8 @@ struct XTPM
     };
 } // namespace azp
 
+static int aniso_generic(const azp_aniso_args* args, const azp_tpm_params* d_params, void* stream);
+
 extern "C" int azp_aniso_forces_planned_two_patch_morse(azp_pair_plan* plan_, const azp_aniso_args* args, const azp_tpm_params* d_params,
                                                         void* stream)
     {
@@ -375,13 +378,15 @@ extern "C" int azp_aniso_forces_planned_two_patch_morse(azp_pair_plan* plan_, co
     if (plan.builds == 0 || plan.N != args->pair.N || plan.nlist_ptr != args->pair.d_nlist || plan.head_ptr != args->pair.d_head_list)
         return AZP_ERROR_INVALID_ARGUMENT; // a plan compiled from a different list is a caller bug
     if (!xtiled_usable(plan, args->pair))
-        return plan.from_cells ? AZP_ERROR_INVALID_ARGUMENT : azp_aniso_forces_two_patch_morse(args, d_params, stream);
+        return plan.from_cells ? AZP_ERROR_INVALID_ARGUMENT : aniso_generic(args, d_params, stream);
     XTPM::KExtra x;
     x.orientation = args->d_orientation;
     x.torque = args->d_torque;
     return launch_xtiled<XTPM>(plan, args->pair, x, d_params, static_cast<hipStream_t>(stream));
     }
 
+// what gpu_compute_pair_aniso_forces<E> forwards to (src/AnisoPotentialPairGPUKernel.cu.inc:21-25): the tile-staged
+// kernel from libazp's own plan cache (pair_auto.hpp) unless the caller asks for the generic kernel
 extern "C" int azp_aniso_forces_two_patch_morse(const azp_aniso_args* args, const azp_tpm_params* d_params,
                                                 void* stream)
     {
@@ -393,6 +398,26 @@ extern "C" int azp_aniso_forces_two_patch_morse(const azp_aniso_args* args, cons
     if (bad > 0) return AZP_SUCCESS;
     if (!args->d_orientation || !args->d_torque || args->pair.shift_mode == AZP_SHIFT_XPLOR)
         return AZP_ERROR_INVALID_ARGUMENT; // HOOMD aniso pairs accept "none" / "shift"
+    if (!auto_plan_wanted(args->pair))
+        return aniso_generic(args, d_params, stream);
+    XTPM::KExtra x;
+    x.orientation = args->d_orientation;
+    x.torque = args->d_torque;
+    return auto_plan_run(
+        args->pair, true, static_cast<hipStream_t>(stream),
+        [&](const AutoLaunch& l)
+            {
+            if (!xtiled_usable(*l.plan, *l.args))
+                return aniso_generic(args, d_params, stream);
+            return launch_xtiled<XTPM>(*l.plan, *l.args, x, d_params, static_cast<hipStream_t>(stream), l.dyn);
+            },
+        [&]() { return aniso_generic(args, d_params, stream); });
+    }
+
+// the generic kernel (arguments validated by the caller)
+static int aniso_generic(const azp_aniso_args* args, const azp_tpm_params* d_params, void* stream)
+    {
+    using namespace azp;
     AnisoKArgs k;
     k.p = make_pair_kargs(args->pair);
     k.orientation = args->d_orientation;

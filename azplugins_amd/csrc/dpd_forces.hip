@@ -9,6 +9,7 @@
 // block per in-range pair, computed in registers, keyed by
 // (seed, timestep, min tag, max tag) so both owners of a pair draw the same
 // number (cross-rank consistency relies on this: :213-231).
+#include "pair_auto.hpp"
 #include "xtiled.hpp"
 
 namespace azp
@@ -298,6 +299,8 @@ struct XDPD
     };
 } // namespace azp
 
+static int dpd_generic(const azp_dpd_args* args, const azp_dpd_params* d_params, void* stream);
+
 static int azp_dpd_validate(const azp_dpd_args* args, const azp_dpd_params* d_params)
     {
     if (!args)
@@ -323,23 +326,40 @@ extern "C" int azp_dpd_forces_planned_general_weight(azp_pair_plan* plan_, const
     if (plan.builds == 0 || plan.N != args->pair.N || plan.nlist_ptr != args->pair.d_nlist || plan.head_ptr != args->pair.d_head_list)
         return AZP_ERROR_INVALID_ARGUMENT; // a plan compiled from a different list is a caller bug
     if (!xtiled_usable(plan, args->pair))
-        return plan.from_cells ? AZP_ERROR_INVALID_ARGUMENT : azp_dpd_forces_general_weight(args, d_params, stream);
+        return plan.from_cells ? AZP_ERROR_INVALID_ARGUMENT : dpd_generic(args, d_params, stream);
     XDPD::KExtra x;
     x.vel = args->d_vel; x.tag = args->d_tag; x.timestep = args->timestep; x.deltaT = args->deltaT; x.T = args->T;
     x.seed = args->seed; x._pad = 0;
     return launch_xtiled<XDPD>(plan, args->pair, x, d_params, static_cast<hipStream_t>(stream));
     }
 
+// what gpu_compute_dpd_forces<E> forwards to (src/PotentialPairDPDThermoGPUKernel.cu.inc:21-24): the tile-staged kernel
+// from libazp's own plan cache (pair_auto.hpp) unless the caller asks for the generic kernel
 extern "C" int azp_dpd_forces_general_weight(const azp_dpd_args* args, const azp_dpd_params* d_params, void* stream)
     {
     using namespace azp;
-    if (!args)
-        return AZP_ERROR_INVALID_ARGUMENT;
-    const int bad = validate_pair_args(&args->pair, d_params);
+    const int bad = azp_dpd_validate(args, d_params);
     if (bad < 0) return bad;
     if (bad > 0) return AZP_SUCCESS;
-    if (!args->d_vel || !args->d_tag || args->pair.shift_mode != AZP_SHIFT_NONE)
-        return AZP_ERROR_INVALID_ARGUMENT; // DPD accepts mode "none" only (src/pair.py:215)
+    if (!auto_plan_wanted(args->pair))
+        return dpd_generic(args, d_params, stream);
+    XDPD::KExtra x;
+    x.vel = args->d_vel; x.tag = args->d_tag; x.timestep = args->timestep; x.deltaT = args->deltaT; x.T = args->T;
+    x.seed = args->seed; x._pad = 0;
+    return auto_plan_run(
+        args->pair, true, static_cast<hipStream_t>(stream),
+        [&](const AutoLaunch& l)
+            {
+            if (!xtiled_usable(*l.plan, *l.args))
+                return dpd_generic(args, d_params, stream);
+            return launch_xtiled<XDPD>(*l.plan, *l.args, x, d_params, static_cast<hipStream_t>(stream), l.dyn);
+            },
+        [&]() { return dpd_generic(args, d_params, stream); });
+    }
+
+static int dpd_generic(const azp_dpd_args* args, const azp_dpd_params* d_params, void* stream)
+    {
+    using namespace azp;
     DPDKArgs k;
     k.p = make_pair_kargs(args->pair);
     k.vel = args->d_vel;

@@ -38,6 +38,15 @@ namespace azp
 extern __device__ unsigned long long g_timeline[8 * 4 * 16384];
 #endif
 
+// Words a speculatively launched tile kernel reads from device memory (pair_auto.hpp): written by the
+// list-check kernel that runs right before it on the same stream.
+struct TileDyn
+    {
+    uint32_t n_shells;   // buffer shells to walk for the displacement measured by the check
+    uint32_t stale;      // != 0: the plan does not describe the list any more -- leave at once (the call is repeated)
+    double bound;        // that displacement (< 0: unknown)
+    };
+
 struct TiledKArgs
     {
     PairKArgs p;
@@ -66,6 +75,7 @@ struct TiledKArgs
     // was at least r_cut + s w away, and the two particles of a pair have closed in by at most the sum of their own
     // displacements <= 2 x the largest one in the tile -- instead of the shells the fastest particle of the whole system
     // dictates. bound_extra is added to every entry (a plan compiled later than the positions the displacements refer to).
+    const TileDyn* dyn;           // NULL: n_shells / bound above are final
     const float* disp;            // n_max entries; NULL: the global bound above
     double shell_w;               // shell width of the plan
     double shell_winv;            // 1 / shell_w (0: no shells)
@@ -404,6 +414,8 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
     const uint32_t first = tile * TB;
     if (first >= a.p.end)
         return;
+    if (a.dyn && a.dyn->stale) // speculative launch on a plan that turned out stale (uniform: whole grid leaves)
+        return;
 
     Coeff c0;
     double ronsq0 = 0.0;
@@ -567,8 +579,8 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
     const unsigned long long tl_t1 = __builtin_amdgcn_s_memrealtime();
 #endif
     // the displacement bound of this tile and the shells it has to walk
-    double bound = a.bound;
-    uint32_t n_shells = a.n_shells;
+    double bound = a.dyn ? a.dyn->bound : a.bound;
+    uint32_t n_shells = a.dyn ? min(a.dyn->n_shells, PLAN_SHELLS) : a.n_shells;
     if (a.disp)
         {
         const float d4 = fmaxf(fmaxf(s_dmax[0], s_dmax[1]), fmaxf(s_dmax[2], s_dmax[3]));
@@ -659,9 +671,9 @@ __global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_til
 
 template<class E, int TPP, int CAP, bool VIRIAL, bool SINGLE, bool XPLOR>
 int launch_tiled_instance2(const PairPlan& plan, const azp_pair_args& args, const typename E::Params* d_params,
-                          hipStream_t stream)
+                          hipStream_t stream, const TileDyn* dyn)
     {
-    TiledKArgs k;
+    TiledKArgs k = {};
     k.p = make_pair_kargs(args);
     k.tile_nstage = plan.d_tile_nstage;
     k.tile_head = plan.d_tile_head;
@@ -677,6 +689,7 @@ int launch_tiled_instance2(const PairPlan& plan, const azp_pair_args& args, cons
     k.core_r = plan.core_r;
     k.sure_r = plan.sure_r;
     fill_local_bound(k, plan, args);
+    k.dyn = dyn;
     k.slice_head = plan.d_slice_head;
     k.cnl = plan.d_cnl;
     // sub-range launches are rounded outwards to whole tiles (a tile computed by
@@ -708,15 +721,15 @@ int launch_tiled_instance2(const PairPlan& plan, const azp_pair_args& args, cons
 
 template<class E, int TPP, int CAP, bool VIRIAL, bool SINGLE>
 int launch_tiled_instance(const PairPlan& plan, const azp_pair_args& args, const typename E::Params* d_params,
-                          hipStream_t stream)
+                          hipStream_t stream, const TileDyn* dyn)
     {
     if (args.shift_mode == AZP_SHIFT_XPLOR)
-        return launch_tiled_instance2<E, TPP, CAP, VIRIAL, SINGLE, true>(plan, args, d_params, stream);
-    return launch_tiled_instance2<E, TPP, CAP, VIRIAL, SINGLE, false>(plan, args, d_params, stream);
+        return launch_tiled_instance2<E, TPP, CAP, VIRIAL, SINGLE, true>(plan, args, d_params, stream, dyn);
+    return launch_tiled_instance2<E, TPP, CAP, VIRIAL, SINGLE, false>(plan, args, d_params, stream, dyn);
     }
 
 template<class E, int TPP, bool VIRIAL, bool SINGLE>
-int launch_tiled_cap(const PairPlan& plan, const azp_pair_args& args, const typename E::Params* d_params, hipStream_t s)
+int launch_tiled_cap(const PairPlan& plan, const azp_pair_args& args, const typename E::Params* d_params, hipStream_t s, const TileDyn* dyn)
     {
     // LDS variant: from the tiles this launch covers (all of them unless a range is given)
     uint32_t cap = plan.cap;
@@ -732,30 +745,31 @@ int launch_tiled_cap(const PairPlan& plan, const azp_pair_args& args, const type
         }
     switch (cap)
         {
-    case 1024: return launch_tiled_instance<E, TPP, 1024, VIRIAL, SINGLE>(plan, args, d_params, s);
-    case 1536: return launch_tiled_instance<E, TPP, 1536, VIRIAL, SINGLE>(plan, args, d_params, s);
-    case 1664: return launch_tiled_instance<E, TPP, 1664, VIRIAL, SINGLE>(plan, args, d_params, s);
-    case 2048: return launch_tiled_instance<E, TPP, 2048, VIRIAL, SINGLE>(plan, args, d_params, s);
-    case 2560: return launch_tiled_instance<E, TPP, 2560, VIRIAL, SINGLE>(plan, args, d_params, s);
+    case 1024: return launch_tiled_instance<E, TPP, 1024, VIRIAL, SINGLE>(plan, args, d_params, s, dyn);
+    case 1536: return launch_tiled_instance<E, TPP, 1536, VIRIAL, SINGLE>(plan, args, d_params, s, dyn);
+    case 1664: return launch_tiled_instance<E, TPP, 1664, VIRIAL, SINGLE>(plan, args, d_params, s, dyn);
+    case 2048: return launch_tiled_instance<E, TPP, 2048, VIRIAL, SINGLE>(plan, args, d_params, s, dyn);
+    case 2560: return launch_tiled_instance<E, TPP, 2560, VIRIAL, SINGLE>(plan, args, d_params, s, dyn);
     default: return AZP_ERROR_INVALID_ARGUMENT;
         }
     }
 
 template<class E, bool VIRIAL, bool SINGLE>
-int launch_tiled_tpp(const PairPlan& plan, const azp_pair_args& args, const typename E::Params* d_params, hipStream_t s)
+int launch_tiled_tpp(const PairPlan& plan, const azp_pair_args& args, const typename E::Params* d_params, hipStream_t s, const TileDyn* dyn)
     {
     switch (plan.tpp)
         {
-    case 1: return launch_tiled_cap<E, 1, VIRIAL, SINGLE>(plan, args, d_params, s);
-    case 2: return launch_tiled_cap<E, 2, VIRIAL, SINGLE>(plan, args, d_params, s);
-    case 4: return launch_tiled_cap<E, 4, VIRIAL, SINGLE>(plan, args, d_params, s);
+    case 1: return launch_tiled_cap<E, 1, VIRIAL, SINGLE>(plan, args, d_params, s, dyn);
+    case 2: return launch_tiled_cap<E, 2, VIRIAL, SINGLE>(plan, args, d_params, s, dyn);
+    case 4: return launch_tiled_cap<E, 4, VIRIAL, SINGLE>(plan, args, d_params, s, dyn);
     default: return AZP_ERROR_INVALID_ARGUMENT;
         }
     }
 
 // Entry: use the plan when it is valid for these arguments, else the generic kernel.
 template<class E>
-int launch_pair_planned(azp_pair_plan* plan_, const azp_pair_args* args, const typename E::Params* d_params, void* stream)
+int launch_pair_planned(azp_pair_plan* plan_, const azp_pair_args* args, const typename E::Params* d_params, void* stream,
+                        const TileDyn* dyn = nullptr)
     {
     if (!plan_)
         return AZP_ERROR_INVALID_ARGUMENT;
@@ -771,10 +785,10 @@ int launch_pair_planned(azp_pair_plan* plan_, const azp_pair_args* args, const t
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool single = (args->ntypes == 1);
     if (args->compute_virial)
-        return single ? launch_tiled_tpp<E, true, true>(plan, *args, d_params, s)
-                      : launch_tiled_tpp<E, true, false>(plan, *args, d_params, s);
-    return single ? launch_tiled_tpp<E, false, true>(plan, *args, d_params, s)
-                  : launch_tiled_tpp<E, false, false>(plan, *args, d_params, s);
+        return single ? launch_tiled_tpp<E, true, true>(plan, *args, d_params, s, dyn)
+                      : launch_tiled_tpp<E, true, false>(plan, *args, d_params, s, dyn);
+    return single ? launch_tiled_tpp<E, false, true>(plan, *args, d_params, s, dyn)
+                  : launch_tiled_tpp<E, false, false>(plan, *args, d_params, s, dyn);
     }
 
 } // namespace azp

@@ -48,6 +48,8 @@ __global__ void __launch_bounds__(256, X::kMinWaves) xtiled_kernel(const TiledKA
     const uint32_t first = tile * 256u;
     if (first >= a.p.end)
         return;
+    if (a.dyn && a.dyn->stale) // speculative launch on a stale plan (pair_auto.hpp)
+        return;
 
     Coeff c0;
     if (SINGLE)
@@ -163,7 +165,7 @@ __global__ void __launch_bounds__(256, X::kMinWaves) xtiled_kernel(const TiledKA
         }
     const bool wide = __syncthreads_or(lane_wide); // also publishes the staged tile
     __builtin_amdgcn_s_setprio(0);
-    uint32_t n_shells = a.n_shells;
+    uint32_t n_shells = a.dyn ? min(a.dyn->n_shells, PLAN_SHELLS) : a.n_shells;
     if (a.disp)
         n_shells = tile_shells_for(to_uniform((double)fmaxf(fmaxf(s_dmax[0], s_dmax[1]), fmaxf(s_dmax[2], s_dmax[3])) + a.bound_extra), a.shell_winv);
 
@@ -254,9 +256,9 @@ __global__ void __launch_bounds__(256, X::kMinWaves) xtiled_kernel(const TiledKA
 
 template<class X, int CAP, bool VIRIAL, bool SINGLE>
 int launch_xtiled_instance(const PairPlan& plan, const azp_pair_args& args, const typename X::KExtra& x, const typename X::Params* d_params,
-                           hipStream_t stream)
+                           hipStream_t stream, const TileDyn* dyn)
     {
-    TiledKArgs k;
+    TiledKArgs k = {};
     k.p = make_pair_kargs(args);
     k.tile_nstage = plan.d_tile_nstage;
     k.tile_head = plan.d_tile_head;
@@ -269,6 +271,7 @@ int launch_xtiled_instance(const PairPlan& plan, const azp_pair_args& args, cons
     k.bound = -1.0;
     k.core_r = k.sure_r = 0.f;
     fill_local_bound(k, plan, args);
+    k.dyn = dyn;
     k.slice_head = plan.d_slice_head;
     k.cnl = plan.d_cnl;
     const uint32_t t0 = k.p.first / 256u, t1 = (k.p.end + 255u) / 256u;
@@ -301,7 +304,8 @@ inline bool xtiled_usable(const PairPlan& plan, const azp_pair_args& args)
     }
 
 template<class X, bool VIRIAL, bool SINGLE>
-int launch_xtiled_cap(const PairPlan& plan, const azp_pair_args& args, const typename X::KExtra& x, const typename X::Params* d_params, hipStream_t s)
+int launch_xtiled_cap(const PairPlan& plan, const azp_pair_args& args, const typename X::KExtra& x, const typename X::Params* d_params, hipStream_t s,
+                      const TileDyn* dyn)
     {
     uint32_t cap = plan.cap;
     if (args.range_count != 0 && !plan.h_tile_nstage.empty())
@@ -315,21 +319,22 @@ int launch_xtiled_cap(const PairPlan& plan, const azp_pair_args& args, const typ
         }
     switch (cap)
         {
-    case 1024: return launch_xtiled_instance<X, 1024, VIRIAL, SINGLE>(plan, args, x, d_params, s);
-    case 1536: return launch_xtiled_instance<X, 1536, VIRIAL, SINGLE>(plan, args, x, d_params, s);
+    case 1024: return launch_xtiled_instance<X, 1024, VIRIAL, SINGLE>(plan, args, x, d_params, s, dyn);
+    case 1536: return launch_xtiled_instance<X, 1536, VIRIAL, SINGLE>(plan, args, x, d_params, s, dyn);
     case 1664:
-    case 2048: return launch_xtiled_instance<X, 2048, VIRIAL, SINGLE>(plan, args, x, d_params, s);
-    case 2560: return launch_xtiled_instance<X, 2560, VIRIAL, SINGLE>(plan, args, x, d_params, s);
+    case 2048: return launch_xtiled_instance<X, 2048, VIRIAL, SINGLE>(plan, args, x, d_params, s, dyn);
+    case 2560: return launch_xtiled_instance<X, 2560, VIRIAL, SINGLE>(plan, args, x, d_params, s, dyn);
     default: return AZP_ERROR_INVALID_ARGUMENT;
         }
     }
 
 template<class X>
-int launch_xtiled(const PairPlan& plan, const azp_pair_args& args, const typename X::KExtra& x, const typename X::Params* d_params, hipStream_t s)
+int launch_xtiled(const PairPlan& plan, const azp_pair_args& args, const typename X::KExtra& x, const typename X::Params* d_params, hipStream_t s,
+                  const TileDyn* dyn = nullptr)
     {
     const bool single = (args.ntypes == 1);
     if (args.compute_virial)
-        return single ? launch_xtiled_cap<X, true, true>(plan, args, x, d_params, s) : launch_xtiled_cap<X, true, false>(plan, args, x, d_params, s);
-    return single ? launch_xtiled_cap<X, false, true>(plan, args, x, d_params, s) : launch_xtiled_cap<X, false, false>(plan, args, x, d_params, s);
+        return single ? launch_xtiled_cap<X, true, true>(plan, args, x, d_params, s, dyn) : launch_xtiled_cap<X, true, false>(plan, args, x, d_params, s, dyn);
+    return single ? launch_xtiled_cap<X, false, true>(plan, args, x, d_params, s, dyn) : launch_xtiled_cap<X, false, false>(plan, args, x, d_params, s, dyn);
     }
 } // namespace azp

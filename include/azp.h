@@ -175,6 +175,11 @@ typedef struct azp_pair_args
                                     at the shells ITS OWN members and listed neighbors can have crossed (twice the
                                     largest of their displacements) instead of what the fastest particle of the whole
                                     system dictates. Exact; NULL = the global bound alone.  */
+    uint64_t list_generation;    /* optional, read by the entry points that keep their own plan cache (azp_pair_forces_*,
+                                    azp_dpd_forces_general_weight, azp_aniso_forces_two_patch_morse): a number the caller
+                                    changes whenever it rewrites the neighbor list (HOOMD: NeighborList::getNumUpdates()
+                                    + 1). Non-zero: the cached plan is recompiled exactly when the number changes and the
+                                    list is not fingerprinted; 0 = unknown, the list is fingerprinted at every call. */
     double displacement_bound_extra; /* added to every d_displacement entry: how far any particle had moved from those
                                     reference positions when the plan was built (0 in the usual flow: plan and list are
                                     built from the same positions) */

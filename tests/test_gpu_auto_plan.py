@@ -197,3 +197,189 @@ def test_hoomd_signature_entry_runs_at_plan_speed():
     print("HOOMD-signature entry: %.3f ms per call with the plan cache, %.3f ms generic" % (ms_auto, ms_generic))
     assert ms_auto < 0.6 * ms_generic
     lib.azp_pair_auto_plan_clear()
+
+
+def _moved_positions(pos, L, r_buff, frac, seed):
+    n = pos.shape[0]
+    tag = np.arange(n, dtype=np.uint64)
+    v = np.stack([syn.normal(seed, tag, c) for c in range(3)], axis=1)
+    v *= (frac * 0.5 * r_buff * syn.u01(seed, tag, 5) / np.linalg.norm(v, axis=1))[:, None]
+    out = pos.copy()
+    out[:, :3] = syn.wrap(pos[:, :3] + v, L)
+    return out
+
+
+def test_dpd_thermostat_behind_its_hoomd_signature(oracle):
+    """gpu_compute_dpd_forces<E> (src/PotentialPairDPDThermoGPUKernel.cu.inc:21-24) forwards to
+    azp_dpd_forces_general_weight: with the plan cache it runs the tile-staged DPD kernel. Particles move,
+    HOOMD rewrites the list in place -- forces equal the oracle's at every call; compile / reuse counters as expected."""
+    import torch
+
+    r_cut, r_buff = 1.0, 0.4
+    cfg = syn.config_dpd(8192)
+    n = cfg["xyz"].shape[0]
+    L = cfg["L"]
+    pos = syn.pos4(cfg["xyz"])
+    vel = np.zeros((n, 4))
+    vel[:, :3] = cfg["vel"]
+    vel[:, 3] = 1.0
+    box = oracle.make_box(L)
+    params = np.atleast_2d(oracle.pack_pair_params("DPDGeneralWeight", cfg["params"]))
+    nl = oracle.build_nlist(pos, box, r_cut + r_buff)
+    a, t = H.gpu_pair_args(pos, (L,), nl, 1, r_cut, 0.0, "none", True, auto_plan=True)
+    cap = int(nl[2].size * 1.2) + 64
+    t["nlist"] = torch.zeros(cap, dtype=torch.int32, device="cuda:0")
+    a.d_nlist = t["nlist"].data_ptr()
+    _write_list(t, nl)
+    p = H._dev(params)
+    v_d, tg = H._dev(vel, np.float64), H._dev(cfg["tag"], np.uint32)
+    d = _lib.DPDArgs()
+    d.d_vel, d.d_tag, d.deltaT, d.T, d.seed = v_d.data_ptr(), tg.data_ptr(), 0.01, 1.0, 7
+    lib = _lib.lib()
+    lib.azp_pair_auto_plan_clear()
+    kw = dict(kT=1.0, dt=0.01, seed=7)
+
+    def call(pos_now, nl_now, step, what):
+        t["pos"].copy_(torch.from_numpy(pos_now))
+        t["force"].fill_(float("nan"))
+        d.pair = a
+        d.timestep = step
+        _lib.check(lib.azp_dpd_forces_general_weight(C.byref(d), p.data_ptr(), H._stream()), what)
+        torch.cuda.synchronize()
+        f_ref, v_ref = oracle.dpd_forces(pos_now, vel, cfg["tag"], box, nl_now, params, r_cut, virial=True, timestep=step, **kw)
+        _close(t["force"].cpu().numpy(), f_ref, what)
+        _close(t["virial"].cpu().numpy(), v_ref, what + " virial")
+        return _lib.auto_plan_stats()
+
+    s0 = _lib.auto_plan_stats()
+    s1 = call(pos, nl, 100, "first call")
+    assert s1["compiles"] - s0["compiles"] == 2 and s1["generic_fallbacks"] == s0["generic_fallbacks"]
+    for k, frac in enumerate((0.0, 0.3, 0.7, 0.99)):
+        s2 = call(_moved_positions(pos, L, r_buff, frac, 21), nl, 101 + k, "moved %.2f" % frac)
+        assert s2["compiles"] == s1["compiles"] and s2["reuses"] == s1["reuses"] + k + 1
+    pos_b = _moved_positions(pos, L, r_buff, 0.99, 21)
+    nl_b = oracle.build_nlist(pos_b, box, r_cut + r_buff)
+    assert nl_b[2].size <= cap
+    _write_list(t, nl_b)
+    s3 = call(pos_b, nl_b, 200, "after rebuild")  # the speculative launch on the stale plan is overwritten
+    assert s3["compiles"] == s2["compiles"] + 1 and s3["generic_fallbacks"] == s0["generic_fallbacks"]
+    s4 = call(_moved_positions(pos_b, L, r_buff, 0.5, 22), nl_b, 201, "moved after rebuild")
+    assert s4["compiles"] == s3["compiles"]
+    lib.azp_pair_auto_plan_clear()
+
+
+def test_two_patch_morse_behind_its_hoomd_signature(oracle):
+    """gpu_compute_pair_aniso_forces<E> (src/AnisoPotentialPairGPUKernel.cu.inc:21-25) forwards to
+    azp_aniso_forces_two_patch_morse: tile-staged kernel from the plan cache, forces AND torques equal the oracle's
+    while particles move and the list is rewritten in place."""
+    import torch
+
+    r_cut, r_buff = 1.6, 0.4
+    cfg = syn.config_tpm(12, 12, 12)
+    L = cfg["L"]
+    pos = syn.pos4(cfg["xyz"])
+    n = pos.shape[0]
+    box = oracle.make_box(L)
+    params = np.atleast_2d(oracle.pack_pair_params("TwoPatchMorse", cfg["params"]))
+    nl = oracle.build_nlist(pos, box, r_cut + r_buff)
+    a, t = H.gpu_pair_args(pos, (L,), nl, 1, r_cut, 0.0, "shift", True, auto_plan=True)
+    cap = int(nl[2].size * 1.3) + 64
+    t["nlist"] = torch.zeros(cap, dtype=torch.int32, device="cuda:0")
+    a.d_nlist = t["nlist"].data_ptr()
+    _write_list(t, nl)
+    p = H._dev(params)
+    q = H._dev(cfg["orientation"], np.float64)
+    tq = torch.full((n, 4), float("nan"), dtype=torch.float64, device="cuda:0")
+    g = _lib.AnisoArgs()
+    g.d_orientation, g.d_torque = q.data_ptr(), tq.data_ptr()
+    lib = _lib.lib()
+    lib.azp_pair_auto_plan_clear()
+
+    def call(pos_now, nl_now, what):
+        t["pos"].copy_(torch.from_numpy(pos_now))
+        t["force"].fill_(float("nan"))
+        tq.fill_(float("nan"))
+        g.pair = a
+        _lib.check(lib.azp_aniso_forces_two_patch_morse(C.byref(g), p.data_ptr(), H._stream()), what)
+        torch.cuda.synchronize()
+        f_ref, t_ref, v_ref = oracle.aniso_forces_tpm(pos_now, cfg["orientation"], box, nl_now, params, r_cut, "shift", virial=True)
+        _close(t["force"].cpu().numpy(), f_ref, what)
+        _close(tq.cpu().numpy()[:, :3], t_ref[:, :3], what + " torque")
+        _close(t["virial"].cpu().numpy(), v_ref, what + " virial")
+        return _lib.auto_plan_stats()
+
+    s0 = _lib.auto_plan_stats()
+    s1 = call(pos, nl, "first call")
+    assert s1["compiles"] - s0["compiles"] == 2 and s1["generic_fallbacks"] == s0["generic_fallbacks"]
+    for k, frac in enumerate((0.4, 0.99)):
+        s2 = call(_moved_positions(pos, L, r_buff, frac, 31), nl, "moved %.2f" % frac)
+        assert s2["compiles"] == s1["compiles"]
+    pos_b = _moved_positions(pos, L, r_buff, 0.99, 31)
+    nl_b = oracle.build_nlist(pos_b, box, r_cut + r_buff)
+    assert nl_b[2].size <= cap
+    _write_list(t, nl_b)
+    s3 = call(pos_b, nl_b, "after rebuild")
+    assert s3["compiles"] == s2["compiles"] + 1 and s3["generic_fallbacks"] == s0["generic_fallbacks"]
+    lib.azp_pair_auto_plan_clear()
+
+
+def test_sampled_fingerprint_rotates_and_generation_counter(oracle):
+    """Lists above 2^22 entries are fingerprinted by row lengths, row starts and two entries of every 8th row, the
+    sampled rows rotating from call to call: a rewrite that keeps every length (here: one row reversed) is noticed
+    within eight calls. A caller that passes azp_pair_args.list_generation is not fingerprinted at all: the plan is
+    recompiled exactly when the number changes."""
+    import torch
+
+    r_cut, r_buff = 3.0, 0.4
+    cfg = syn.config_plj_sc(14)
+    L = cfg["L"]
+    pos = syn.pos4(cfg["xyz"])
+    box = oracle.make_box(L)
+    params = np.atleast_2d(oracle.pack_pair_params("PerturbedLennardJones", cfg["params"]))
+    nl = oracle.build_nlist(pos, box, r_cut + r_buff)
+    a, t = H.gpu_pair_args(pos, (L,), nl, 1, r_cut, 0.0, "shift", False, auto_plan=True)
+    a.size_nlist = (1 << 22) + 1   # claim a long list: the sampled fingerprint
+    p = H._dev(params)
+    lib = _lib.lib()
+    lib.azp_pair_auto_plan_clear()
+    fn = lib.azp_pair_forces_perturbed_lennard_jones
+
+    def call(nl_now, what):
+        t["force"].fill_(float("nan"))
+        _lib.check(fn(C.byref(a), p.data_ptr(), H._stream()), what)
+        torch.cuda.synchronize()
+        f_ref = oracle.pair_forces("PerturbedLennardJones", pos, box, nl_now, params, r_cut, 0.0, "shift", nthreads=8)
+        _close(t["force"].cpu().numpy(), f_ref, what)
+        return _lib.auto_plan_stats()
+
+    s1 = call(nl, "first")
+    s2 = call(nl, "second")
+    assert s2["compiles"] == s1["compiles"]
+    # reverse the MIDDLE entries of one row (the sample reads the last and the middle entry of a sampled row: moving
+    # the entries changes the middle one). The set of neighbors is the same, so the forces stay right either way;
+    # what is asserted is that the change is seen within eight calls.
+    i = 5
+    h, k = int(nl[1][i]), int(nl[0][i])
+    nl_c = (nl[0], nl[1], nl[2].copy())
+    nl_c[2][h:h + k - 1] = nl[2][h:h + k - 1][::-1]
+    _write_list(t, nl_c)
+    seen = None
+    for c in range(8):
+        s = call(nl_c, "rotating %d" % c)
+        if s["compiles"] > s2["compiles"]:
+            seen = c
+            break
+    assert seen is not None
+    # generation counter: no fingerprint; recompiled exactly when the number changes
+    lib.azp_pair_auto_plan_clear()
+    a.list_generation = 41
+    g0 = _lib.auto_plan_stats()
+    g1 = call(nl_c, "generation 41")
+    assert g1["compiles"] > g0["compiles"]
+    _write_list(t, nl)       # rewritten in place, same generation: the caller vouches that nothing changed
+    g2 = call(nl, "generation 41 again (same neighbor sets)")
+    assert g2["compiles"] == g1["compiles"]
+    a.list_generation = 42
+    g3 = call(nl, "generation 42")
+    assert g3["compiles"] == g2["compiles"] + 1
+    lib.azp_pair_auto_plan_clear()

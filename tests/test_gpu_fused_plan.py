@@ -225,15 +225,25 @@ def test_fused_plan_local_displacement_bound(oracle, few):
     f_ref = oracle.pair_forces(PLJ, moved, box, nl, params, r_cut, 0.0, "shift", nthreads=8)
     r_wca = 2.0 ** (1.0 / 6.0) * cfg["params"]["sigma"]
     disp = np.nextafter(np.linalg.norm(v, axis=1).astype(np.float32) * np.float32(1.000001), np.float32(np.inf))
-    f_gpu, info = fused_forces(PLJ, pos0, (L,), params, r_cut, r_buff, mode="shift", moved=moved, bound=float(disp.max()), disp=disp,
-                               r_inner=r_wca + r_buff + 1e-3)
-    assert info["valid"] == 1 and info["core_radius"] > 0 and info["sure_radius"] > 0
-    assert_close(f_gpu, f_ref)
-    # the same launch with the global bound alone gives the same bits (both are exact evaluations of the same pairs
-    # in the same order; only the number of skipped out-of-range entries differs)
-    f_glob, _ = fused_forces(PLJ, pos0, (L,), params, r_cut, r_buff, mode="shift", moved=moved, bound=float(disp.max()),
-                             r_inner=r_wca + r_buff + 1e-3)
-    assert np.array_equal(f_gpu, f_glob)
+    from azplugins_amd import _lib
+
+    results = []
+    for phases in (1, 0):  # the row phases of the tile kernel (off by default) on and off
+        old = _lib.lib().azp_tuning_set(1, phases)
+        try:
+            f_gpu, info = fused_forces(PLJ, pos0, (L,), params, r_cut, r_buff, mode="shift", moved=moved, bound=float(disp.max()), disp=disp,
+                                       r_inner=r_wca + r_buff + 1e-3)
+            assert info["valid"] == 1 and info["core_radius"] > 0 and info["sure_radius"] > 0
+            assert_close(f_gpu, f_ref)
+            # the same launch with the global bound alone gives the same bits (both are exact evaluations of the same
+            # pairs in the same order; only the number of skipped out-of-range entries differs)
+            f_glob, _ = fused_forces(PLJ, pos0, (L,), params, r_cut, r_buff, mode="shift", moved=moved, bound=float(disp.max()),
+                                     r_inner=r_wca + r_buff + 1e-3)
+            assert np.array_equal(f_gpu, f_glob)
+            results.append(f_gpu)
+        finally:
+            _lib.lib().azp_tuning_set(1, old)
+    assert_close(results[0], results[1])
 
 
 def test_fused_plan_row_capacity_protocol(oracle):
