@@ -60,6 +60,48 @@ __device__ __forceinline__ double3 cross3(const double3& a, const double3& b)
     return make_double3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
     }
 
+// One TwoPatchMorse pair (src/AnisoPairEvaluatorTwoPatchMorse.h:127-215): force on i, the torque on i (before its
+// accumulation), the pair energy. U = (U_Morse(r) - U_shift) Omega(gamma_i) Omega(gamma_j), gamma = u . n, u = dr / r,
+// Omega(g) = 1 / (1 + exp(-omega (g^2 - alpha))). Written for the FP64 issue rate of gfx950: one reciprocal square
+// root gives r and 1 / r; the reciprocals of the two sigmoid denominators are Newton-refined v_rcp_f64; and the
+// perpendicular directors n_perp = -u x (u x n) = n - gamma u are never formed -- the force is assembled as
+// F = a u + b_i n_i + b_j n_j with three scalar coefficients (9 FMAs instead of two double cross products).
+__device__ __forceinline__ void tpm_pair(const TPMCoeff& c, const double3& n_i, const double3& n_j, double dx, double dy, double dz,
+                                         double rsq, double (&F)[3], double (&T)[3], double& e)
+    {
+    const double rinv = fast_rsqrt(rsq);
+    const double r = rsq * rinv;
+    const double ux = dx * rinv, uy = dy * rinv, uz = dz * rinv;
+    double UMorse = -c.M_d;
+    double dUMorse_dr = 0.0;
+    if (r > c.r_eq || c.repulsion)
+        {
+        const double Morse_exp = exp(-(r - c.r_eq) * c.M_rinv);
+        const double one_minus_exp = 1.0 - Morse_exp;
+        UMorse = c.M_d * __builtin_fma(one_minus_exp, one_minus_exp, -1.0);
+        dUMorse_dr = 2.0 * c.M_d * c.M_rinv * Morse_exp * one_minus_exp;
+        }
+    const double gi = __builtin_fma(uz, n_i.z, __builtin_fma(uy, n_i.y, ux * n_i.x));
+    const double gj = __builtin_fma(uz, n_j.z, __builtin_fma(uy, n_j.y, ux * n_j.x));
+    const double ei = exp(-c.omega * __builtin_fma(gi, gi, -c.alpha));
+    const double ej = exp(-c.omega * __builtin_fma(gj, gj, -c.alpha));
+    const double Oi = fast_rcp(1.0 + ei), Oj = fast_rcp(1.0 + ej);
+    const double OO = Oi * Oj;
+    e = (UMorse - c.U_shift) * OO;
+    const double w2 = 2.0 * c.omega * UMorse * OO;   // dU/dgamma_i = w2 gamma_i e_i Omega_i, likewise j
+    const double dU_dgi = w2 * gi * ei * Oi;
+    const double dU_dgj = w2 * gj * ej * Oj;
+    const double bi = -rinv * dU_dgi, bj = -rinv * dU_dgj;
+    const double a = -__builtin_fma(bi, gi, __builtin_fma(bj, gj, dUMorse_dr * OO));
+    F[0] = __builtin_fma(a, ux, __builtin_fma(bi, n_i.x, bj * n_j.x));
+    F[1] = __builtin_fma(a, uy, __builtin_fma(bi, n_i.y, bj * n_j.y));
+    F[2] = __builtin_fma(a, uz, __builtin_fma(bi, n_i.z, bj * n_j.z));
+    // torque on i: dU/dgamma_i (u x n_i)
+    T[0] = dU_dgi * __builtin_fma(uy, n_i.z, -uz * n_i.y);
+    T[1] = dU_dgi * __builtin_fma(uz, n_i.x, -ux * n_i.z);
+    T[2] = dU_dgi * __builtin_fma(ux, n_i.y, -uy * n_i.x);
+    }
+
 template<int TPP, bool VIRIAL, bool SINGLE, bool WRAP>
 __device__ __forceinline__ void aniso_loop(const AnisoKArgs& a, const TPMCoeff* __restrict__ s_coeff,
                                            const TPMCoeff& c0, uint32_t sub, uint32_t n, uint64_t head, double3 pi,
@@ -87,46 +129,11 @@ __device__ __forceinline__ void aniso_loop(const AnisoKArgs& a, const TPMCoeff* 
             {
             const double4 qj = load_scalar4(a.orientation, j);
             const double3 n_j = patch_director(qj);
-            const double rinv = 1.0 / sqrt(rsq);
-            const double r = 1.0 / rinv;
-            const double3 u = make_double3(dx * rinv, dy * rinv, dz * rinv);
-
-            double UMorse = -c.M_d;
-            double dUMorse_dr = 0.0;
-            if (r > c.r_eq || c.repulsion)
-                {
-                const double Morse_exp = exp(-(r - c.r_eq) * c.M_rinv);
-                const double one_minus_exp = 1.0 - Morse_exp;
-                UMorse = c.M_d * (one_minus_exp * one_minus_exp - 1.0);
-                dUMorse_dr = 2.0 * c.M_d * c.M_rinv * Morse_exp * one_minus_exp;
-                }
-            const double gamma_i = u.x * n_i.x + u.y * n_i.y + u.z * n_i.z;
-            const double gamma_i_exp = exp(-c.omega * (gamma_i * gamma_i - c.alpha));
-            const double Omega_i = 1.0 / (1.0 + gamma_i_exp);
-            const double gamma_j = u.x * n_j.x + u.y * n_j.y + u.z * n_j.z;
-            const double gamma_j_exp = exp(-c.omega * (gamma_j * gamma_j - c.alpha));
-            const double Omega_j = 1.0 / (1.0 + gamma_j_exp);
-
-            const double OO = Omega_i * Omega_j;
-            const double e = (UMorse - c.U_shift) * OO;
-            const double dU_dr = dUMorse_dr * OO;
-            const double dU_dgi = 2.0 * c.omega * gamma_i * gamma_i_exp * Omega_i * Omega_i * UMorse * Omega_j;
-            const double dU_dgj = 2.0 * c.omega * gamma_j * gamma_j_exp * Omega_j * Omega_j * UMorse * Omega_i;
-
-            // n_perp = cross(-u, cross(u, n))
-            const double3 rxni = cross3(u, n_i);
-            const double3 rxnj = cross3(u, n_j);
-            const double3 mu = make_double3(-u.x, -u.y, -u.z);
-            const double3 nip = cross3(mu, rxni);
-            const double3 njp = cross3(mu, rxnj);
-
-            const double Fx = -dU_dr * u.x - rinv * (dU_dgi * nip.x + dU_dgj * njp.x);
-            const double Fy = -dU_dr * u.y - rinv * (dU_dgi * nip.y + dU_dgj * njp.y);
-            const double Fz = -dU_dr * u.z - rinv * (dU_dgi * nip.z + dU_dgj * njp.z);
+            double F[3], T[3], e;
+            tpm_pair(c, n_i, n_j, dx, dy, dz, rsq, F, T, e);
+            const double Fx = F[0], Fy = F[1], Fz = F[2];
             f[0] += Fx; f[1] += Fy; f[2] += Fz;
-            t[0] = __builtin_fma(dU_dgi, rxni.x, t[0]);
-            t[1] = __builtin_fma(dU_dgi, rxni.y, t[1]);
-            t[2] = __builtin_fma(dU_dgi, rxni.z, t[2]);
+            t[0] += T[0]; t[1] += T[1]; t[2] += T[2];
             pe += e;
             if (VIRIAL)
                 {
@@ -307,41 +314,11 @@ struct XTPM
         {
         const double3 n_i = o.n;
         const double3 n_j = make_double3(nj[0], nj[1], nj[2]);
-        const double rinv = 1.0 / sqrt(rsq);
-        const double r = 1.0 / rinv;
-        const double3 u = make_double3(dx * rinv, dy * rinv, dz * rinv);
-        double UMorse = -c.M_d;
-        double dUMorse_dr = 0.0;
-        if (r > c.r_eq || c.repulsion)
-            {
-            const double Morse_exp = exp(-(r - c.r_eq) * c.M_rinv);
-            const double one_minus_exp = 1.0 - Morse_exp;
-            UMorse = c.M_d * (one_minus_exp * one_minus_exp - 1.0);
-            dUMorse_dr = 2.0 * c.M_d * c.M_rinv * Morse_exp * one_minus_exp;
-            }
-        const double gamma_i = u.x * n_i.x + u.y * n_i.y + u.z * n_i.z;
-        const double gamma_i_exp = exp(-c.omega * (gamma_i * gamma_i - c.alpha));
-        const double Omega_i = 1.0 / (1.0 + gamma_i_exp);
-        const double gamma_j = u.x * n_j.x + u.y * n_j.y + u.z * n_j.z;
-        const double gamma_j_exp = exp(-c.omega * (gamma_j * gamma_j - c.alpha));
-        const double Omega_j = 1.0 / (1.0 + gamma_j_exp);
-        const double OO = Omega_i * Omega_j;
-        const double e = (UMorse - c.U_shift) * OO;
-        const double dU_dr = dUMorse_dr * OO;
-        const double dU_dgi = 2.0 * c.omega * gamma_i * gamma_i_exp * Omega_i * Omega_i * UMorse * Omega_j;
-        const double dU_dgj = 2.0 * c.omega * gamma_j * gamma_j_exp * Omega_j * Omega_j * UMorse * Omega_i;
-        const double3 rxni = cross3(u, n_i);
-        const double3 rxnj = cross3(u, n_j);
-        const double3 mu = make_double3(-u.x, -u.y, -u.z);
-        const double3 nip = cross3(mu, rxni);
-        const double3 njp = cross3(mu, rxnj);
-        const double Fx = -dU_dr * u.x - rinv * (dU_dgi * nip.x + dU_dgj * njp.x);
-        const double Fy = -dU_dr * u.y - rinv * (dU_dgi * nip.y + dU_dgj * njp.y);
-        const double Fz = -dU_dr * u.z - rinv * (dU_dgi * nip.z + dU_dgj * njp.z);
+        double F[3], T[3], e;
+        tpm_pair(c, n_i, n_j, dx, dy, dz, rsq, F, T, e);
+        const double Fx = F[0], Fy = F[1], Fz = F[2];
         a.f[0] += Fx; a.f[1] += Fy; a.f[2] += Fz;
-        a.t[0] = __builtin_fma(dU_dgi, rxni.x, a.t[0]);
-        a.t[1] = __builtin_fma(dU_dgi, rxni.y, a.t[1]);
-        a.t[2] = __builtin_fma(dU_dgi, rxni.z, a.t[2]);
+        a.t[0] += T[0]; a.t[1] += T[1]; a.t[2] += T[2];
         a.pe += e;
         if (VIRIAL)
             {

@@ -49,8 +49,8 @@ __device__ __forceinline__ DPDCoeff dpd_prepare(const azp_dpd_params& p, double 
 __device__ __forceinline__ double weight_pow(double x, double half_s)
     {
     if (half_s == 1.0) return x;
-    if (half_s == 0.5) return sqrt(x);
-    if (half_s == 0.25) return sqrt(sqrt(x));
+    if (half_s == 0.5) return fast_sqrt(x);
+    if (half_s == 0.25) return fast_sqrt(fast_sqrt(x));
     return pow(x, half_s);
     }
 
@@ -82,8 +82,8 @@ __device__ __forceinline__ void dpd_loop(const DPDKArgs& a, const DPDCoeff* __re
             const uint32_t tagj = a.tag[j];
             const double rdotv = dx * (vi.x - vj.x) + dy * (vi.y - vj.y) + dz * (vi.z - vj.z);
             const double alpha = dpd_alpha((uint16_t)a.seed, tagi, tagj, a.timestep);
-            const double rinv = 1.0 / sqrt(rsq);
-            const double r = 1.0 / rinv;
+            const double rinv = fast_rsqrt(rsq);
+            const double r = rsq * rinv;
             const double force_divr_cons = c.A * (rinv - c.rcutinv);
             const double wR = weight_pow(1.0 - r * c.rcutinv, c.half_s) * rinv;
             double force_divr = force_divr_cons - c.gamma * wR * wR * rdotv;
@@ -271,8 +271,8 @@ struct XDPD
         {
         const double rdotv = dx * (o.v.x - vj[0]) + dy * (o.v.y - vj[1]) + dz * (o.v.z - vj[2]);
         const double alpha = dpd_alpha((uint16_t)x.seed, o.tag, tagj, x.timestep);
-        const double rinv = 1.0 / sqrt(rsq);
-        const double r = 1.0 / rinv;
+        const double rinv = fast_rsqrt(rsq);
+        const double r = rsq * rinv;
         const double force_divr_cons = c.A * (rinv - c.rcutinv);
         const double wR = weight_pow(1.0 - r * c.rcutinv, c.half_s) * rinv;
         double force_divr = force_divr_cons - c.gamma * wR * wR * rdotv;

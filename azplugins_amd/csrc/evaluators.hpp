@@ -100,6 +100,12 @@ struct EvalPLJ
     // than eval (no blended offset, no 64-bit select, one Newton step less), and the
     // reciprocals of a batch of four pairs share one v_rcp_f64 (rcp4).
     static constexpr bool kSplitEnergy = true;
+    // waves per SIMD the tile kernel is compiled for (its register budget: 512 / kTileWaves VGPRs per lane)
+#ifndef AZP_TILED_WAVES_PER_SIMD
+    static constexpr int kTileWaves = 4;
+#else
+    static constexpr int kTileWaves = AZP_TILED_WAVES_PER_SIMD;
+#endif
     // Reciprocals of four squared separations from ONE v_rcp_f64: R = 1 / (a b c d) (seed
     // + one Newton step, relative error ~2e-15 like fast_rcp1), then 1/(ab) = cd R,
     // 1/(cd) = ab R, 1/a = b / (ab), ...: 9 multiplies + 1 rcp + 2 fma instead of 4 rcp +
@@ -178,31 +184,36 @@ struct EvalHertz
     {
     typedef azp_hertz_params Params;
     static constexpr bool kSplitEnergy = false;
+#ifndef AZP_TW_HERTZ
+#define AZP_TW_HERTZ 4
+#endif
+    static constexpr int kTileWaves = AZP_TW_HERTZ; // waves per SIMD of the tile kernel (register budget)
     struct Coeff
         {
-        double rcutsq, epsilon, rcut, rcutinv;
+        double rcutsq, epsilon, rcutinv, f_pref; // f_pref = 2.5 epsilon / r_cut
         };
     static __device__ __forceinline__ Coeff prepare(const Params& p, double rcutsq, bool)
         {
         Coeff c;
         c.rcutsq = (p.epsilon != 0.0) ? rcutsq : -1.0;
         c.epsilon = p.epsilon;
-        c.rcut = sqrt(rcutsq);
-        c.rcutinv = 1.0 / c.rcut;
+        c.rcutinv = 1.0 / sqrt(rcutsq);
+        c.f_pref = 2.5 * p.epsilon * c.rcutinv;
         return c;
         }
+    // U = eps x^(5/2), x = 1 - r / r_cut; F / r = (5 / 2) eps x^(3/2) / (r r_cut). One reciprocal square root
+    // gives r and 1 / r, a second one x^(1/2): no division, no IEEE square root.
     static __device__ __forceinline__ bool eval(const Coeff& c, double rsq, double& force_divr, double& pair_eng)
         {
         force_divr = 0.0;
         pair_eng = 0.0;
         if (rsq < c.rcutsq)
             {
-            const double r = sqrt(rsq);
-            const double x = 1.0 - r / c.rcut;
-            const double xsqrt = sqrt(x);
-            const double ex3p2 = c.epsilon * x * xsqrt;
-            force_divr = 2.5 * ex3p2 / (r * c.rcut);
-            pair_eng = ex3p2 * x;
+            const double rinv = fast_rsqrt(rsq);
+            const double x = __builtin_fma(-rsq * rinv, c.rcutinv, 1.0);
+            const double x3p2 = x * fast_sqrt(x);
+            force_divr = c.f_pref * x3p2 * rinv;
+            pair_eng = c.epsilon * x3p2 * x;
             return true;
             }
         return false;
@@ -216,6 +227,10 @@ struct EvalYukawa
     {
     typedef azp_yukawa_params Params;
     static constexpr bool kSplitEnergy = false;
+#ifndef AZP_TW_YUKAWA
+#define AZP_TW_YUKAWA 3
+#endif
+    static constexpr int kTileWaves = AZP_TW_YUKAWA; // waves per SIMD of the tile kernel (register budget)
     struct Coeff
         {
         double rcutsq, epsilon, kappa, delta, e_cut;
@@ -241,11 +256,11 @@ struct EvalYukawa
         pair_eng = 0.0;
         if (rsq < c.rcutsq)
             {
-            const double r = sqrt(rsq);
-            const double r_delta = r - c.delta;
-            const double r_delta_inv = 1.0 / r_delta;
+            const double rinv = fast_rsqrt(rsq);
+            const double r_delta = __builtin_fma(rsq, rinv, -c.delta);
+            const double r_delta_inv = fast_rcp(r_delta);
             const double e = c.epsilon * exp(-c.kappa * r_delta) * r_delta_inv;
-            force_divr = e * (c.kappa + r_delta_inv) / r;
+            force_divr = e * (c.kappa + r_delta_inv) * rinv;
             pair_eng = e - c.e_cut;
             return true;
             }
@@ -254,117 +269,130 @@ struct EvalYukawa
     };
 
 // ---------------------------------------------------------------------------
-// Colloid -- src/PairEvaluatorColloid.h:101-269
-// kind is fixed per type pair: 0 solvent-solvent, 1 colloid-solvent,
+// Colloid -- src/PairEvaluatorColloid.h:101-269 (the integrated Lennard-Jones potentials of Everaers and
+// Ejtehadi). kind is fixed per type pair: 0 solvent-solvent, 1 colloid-solvent,
 // 2 colloid-colloid (dispatch at :239-262).
 // ---------------------------------------------------------------------------
 struct EvalColloid
     {
     typedef azp_colloid_params Params;
     static constexpr bool kSplitEnergy = false;
+#ifndef AZP_TW_COLLOID
+#define AZP_TW_COLLOID 2
+#endif
+    static constexpr int kTileWaves = AZP_TW_COLLOID; // waves per SIMD of the tile kernel (register budget)
+    // Everything that depends on the type pair alone is folded into the coefficients once per kernel; the pair
+    // loop sees polynomials in Horner form and ONE reciprocal per branch (colloid-colloid: of the product of the
+    // four surface-to-surface factors, shared four ways as EvalPLJ::rcp4 shares it among four pairs).
     struct Coeff
         {
-        double rcutsq, A, ai, aj, sigma_3, sigma_6, e_cut;
-        int kind;
-        int _pad;
+        double rcutsq, e_cut;
+        int kind, _pad;
+        double A;
+        // kind 0 (solvent-solvent): U = c1 r^-6 (s6 r^-6 - 1), F / r = r^-8 (f12 r^-6 - f6)
+        double c1, s6, f12, f6;
+        // kind 1 (colloid-solvent), a = the colloid's radius, m = a^2 - r^2 (< 0), t = r^2:
+        //   U = pre / m^3 (2/9) (1 - s6 pe(t) / m^6),  F / r = (4/15) pre / m^4 (s6 pf(t) / m^6 - 5)
+        double a2, pre, pe0, pe1, pe2, pf0, pf1, pf2;
+        // kind 2 (colloid-colloid): S = a_1 + a_2, D = a_1 - a_2, k0 = a_1 a_2
+        double S, D, k0, rep; // rep = A sigma^6 / 37800
         };
 
-    template<bool FORCE>
-    static __device__ __forceinline__ double solvent_solvent(const Coeff& c, double& force_divr, double rsq)
+    static __device__ __forceinline__ double solvent_solvent(const Coeff& c, bool want_force, double& force_divr, double rsq)
         {
-        const double r2inv = 1.0 / rsq;
+        const double r2inv = fast_rcp(rsq);
         const double r6inv = r2inv * r2inv * r2inv;
-        const double c1 = c.A * c.sigma_6 / 36.0;
-        if (FORCE)
-            force_divr = 6.0 * c1 * r2inv * r6inv * (2.0 * c.sigma_6 * r6inv - 1.0);
-        return c1 * r6inv * (c.sigma_6 * r6inv - 1.0);
+        if (want_force)
+            force_divr = r2inv * r6inv * __builtin_fma(c.f12, r6inv, -c.f6);
+        return c.c1 * r6inv * __builtin_fma(c.s6, r6inv, -1.0);
         }
-    template<bool FORCE>
-    static __device__ __forceinline__ double colloid_solvent(const Coeff& c, double& force_divr, double rsq)
+    static __device__ __forceinline__ double colloid_solvent(const Coeff& c, bool want_force, double& force_divr, double rsq)
         {
-        const double a = (c.ai > c.aj) ? c.ai : c.aj;
-        const double asq = a * a;
-        const double asq_minus_rsq = asq - rsq;
-        const double rsqsq = rsq * rsq;
-        const double amr3 = asq_minus_rsq * asq_minus_rsq * asq_minus_rsq;
-        const double amr6 = amr3 * amr3;
-        const double fR = c.sigma_3 * c.A * a * asq / amr3;
-        if (FORCE)
+        const double im = fast_rcp(c.a2 - rsq);
+        const double im3 = im * im * im;
+        const double w = c.s6 * im3 * im3; // sigma^6 / m^6
+        const double u = c.pre * im3;      // sigma^3 A a^3 / m^3
+        if (want_force)
             {
-            force_divr = (4.0 / 15.0) * fR
-                         * (2.0 * (asq + rsq) * (asq * (5.0 * asq + 22.0 * rsq) + 5.0 * rsqsq) * c.sigma_6 / amr6 - 5.0)
-                         / asq_minus_rsq;
+            const double pf = __builtin_fma(__builtin_fma(__builtin_fma(10.0, rsq, c.pf2), rsq, c.pf1), rsq, c.pf0);
+            force_divr = (4.0 / 15.0) * u * im * __builtin_fma(pf, w, -5.0);
             }
-        return (2.0 / 9.0) * fR
-               * (1.0 - (asq * (asq * (asq / 3.0 + 3.0 * rsq) + 4.2 * rsqsq) + rsq * rsqsq) * c.sigma_6 / amr6);
+        const double pe = __builtin_fma(__builtin_fma(__builtin_fma(1.0, rsq, c.pe2), rsq, c.pe1), rsq, c.pe0);
+        return (2.0 / 9.0) * u * __builtin_fma(-pe, w, 1.0);
         }
-    template<bool FORCE>
-    static __device__ __forceinline__ double colloid_colloid(const Coeff& c, double& force_divr, double rsq)
+    // One of the four repulsive terms: x = c +- r, xinv = 1 / x, s = +1 (c = S) or -1 (c = D).
+    //   h = ((x + 5 c) x + 30 s k0) x^-7      (energy)
+    //   g = (42 s k0 / x + 6 c + x) x^-7      (its r-derivative, up to the sign of dx / dr)
+    static __device__ __forceinline__ void rep_term(double x, double xinv, double cc, double sk0, double& h, double& g)
         {
-        const double r = sqrt(rsq);
-        const double k0 = c.ai * c.aj;
-        const double k1 = c.ai + c.aj;
-        const double k2 = c.ai - c.aj;
-        const double k3 = k1 + r;
-        const double k4 = k1 - r;
-        const double k5 = k2 + r;
-        const double k6 = k2 - r;
-        const double k7 = 1.0 / (k3 * k4);
-        const double k8 = 1.0 / (k5 * k6);
-
-        const double k3inv = 1.0 / k3;
-        double g0 = k3inv * k3inv; g0 *= g0 * g0; g0 *= k3inv;
-        const double k4inv = 1.0 / k4;
-        double g1 = k4inv * k4inv; g1 *= g1 * g1; g1 *= k4inv;
-        const double k5inv = 1.0 / k5;
-        double g2 = k5inv * k5inv; g2 *= g2 * g2; g2 *= k5inv;
-        const double k6inv = 1.0 / k6;
-        double g3 = k6inv * k6inv; g3 *= g3 * g3; g3 *= k6inv;
-
-        const double h0 = ((k3 + 5.0 * k1) * k3 + 30.0 * k0) * g0;
-        const double h1 = ((k4 + 5.0 * k1) * k4 + 30.0 * k0) * g1;
-        const double h2 = ((k5 + 5.0 * k2) * k5 - 30.0 * k0) * g2;
-        const double h3 = ((k6 + 5.0 * k2) * k6 - 30.0 * k0) * g3;
-
-        g0 *= 42.0 * k0 * k3inv + 6.0 * k1 + k3;
-        g1 *= 42.0 * k0 * k4inv + 6.0 * k1 + k4;
-        g2 *= -42.0 * k0 * k5inv + 6.0 * k2 + k5;
-        g3 *= -42.0 * k0 * k6inv + 6.0 * k2 + k6;
-
-        const double rinv = 1.0 / r;
-        const double fR = c.A * c.sigma_6 * rinv / 37800.0;
-        double pair_eng = fR * (h0 - h1 - h2 + h3);
-        if (FORCE)
+        const double x2 = xinv * xinv;
+        const double x7 = x2 * x2 * x2 * xinv;
+        h = __builtin_fma(x + 5.0 * cc, x, 30.0 * sk0) * x7;
+        g = (__builtin_fma(42.0 * sk0, xinv, x) + 6.0 * cc) * x7;
+        }
+    static __device__ __forceinline__ double colloid_colloid(const Coeff& c, bool want_force, double& force_divr, double rsq)
+        {
+        const double rinv = fast_rsqrt(rsq);
+        const double r = rsq * rinv;
+        // the four factors of (S^2 - r^2) (D^2 - r^2) and their reciprocals from one v_rcp_f64
+        const double p = c.S + r, q = c.S - r, u = c.D + r, w = c.D - r;
+        const double pq = p * q, uw = u * w;
+        const double R = fast_rcp(pq * uw);
+        const double ipq = uw * R, iuw = pq * R; // 1 / (S^2 - r^2), 1 / (D^2 - r^2)
+        const double ip = q * ipq, iq = p * ipq, iu = w * iuw, iw = u * iuw;
+        double h0, h1, h2, h3, g0, g1, g2, g3;
+        rep_term(p, ip, c.S, c.k0, h0, g0);
+        rep_term(q, iq, c.S, c.k0, h1, g1);
+        rep_term(u, iu, c.D, -c.k0, h2, g2);
+        rep_term(w, iw, c.D, -c.k0, h3, g3);
+        const double fR = c.rep * rinv;
+        const double e_rep = fR * ((h0 - h1) - (h2 - h3));
+        if (want_force)
             {
-            const double dUR = pair_eng * rinv + 5.0 * fR * (g0 + g1 - g2 - g3);
-            const double dUA = -c.A / 3.0 * r * ((2.0 * k0 * k7 + 1.0) * k7 + (2.0 * k0 * k8 - 1.0) * k8);
-            force_divr = (dUR + dUA) * rinv;
+            const double dUR = __builtin_fma(e_rep, rinv, 5.0 * fR * ((g0 + g1) - (g2 + g3)));
+            const double ta = __builtin_fma(2.0 * c.k0, ipq, 1.0) * ipq + __builtin_fma(2.0 * c.k0, iuw, -1.0) * iuw;
+            // -dU/dr / r, attractive part: -(A / 3) r (...) / r
+            force_divr = __builtin_fma(dUR, rinv, -(c.A / 3.0) * ta);
             }
-        pair_eng += c.A / 6.0 * (2.0 * k0 * (k7 + k8) - log(k8 / k7));
-        return pair_eng;
+        // ln((D^2 - r^2)^-1 / (S^2 - r^2)^-1) = ln((S^2 - r^2) / (D^2 - r^2)): the ratio is there already
+        return e_rep + (c.A / 6.0) * (2.0 * c.k0 * (ipq + iuw) - log(pq * iuw));
+        }
+    static __device__ __forceinline__ double branch(const Coeff& c, bool want_force, double& force_divr, double rsq)
+        {
+        if (c.kind == 0)
+            return solvent_solvent(c, want_force, force_divr, rsq);
+        if (c.kind == 2)
+            return colloid_colloid(c, want_force, force_divr, rsq);
+        return colloid_solvent(c, want_force, force_divr, rsq);
         }
 
     static __device__ __forceinline__ Coeff prepare(const Params& p, double rcutsq, bool energy_shift)
         {
         Coeff c;
+        const double s3 = p.sigma_3, s6 = s3 * s3;
         c.rcutsq = (p.A != 0.0) ? rcutsq : -1.0;
         c.A = p.A;
-        c.ai = p.a_1;
-        c.aj = p.a_2;
-        c.sigma_3 = p.sigma_3;
-        c.sigma_6 = p.sigma_3 * p.sigma_3;
         c.kind = (p.a_1 == 0.0 && p.a_2 == 0.0) ? 0 : ((p.a_1 != 0.0 && p.a_2 != 0.0) ? 2 : 1);
         c._pad = 0;
+        c.s6 = s6;
+        c.c1 = p.A * s6 / 36.0;
+        c.f12 = 12.0 * c.c1 * s6;
+        c.f6 = 6.0 * c.c1;
+        const double a = (p.a_1 > p.a_2) ? p.a_1 : p.a_2, a2 = a * a, a4 = a2 * a2;
+        c.a2 = a2;
+        c.pre = s3 * p.A * a * a2;
+        // energy polynomial (t^3 + 4.2 a^2 t^2 + 3 a^4 t + a^6 / 3), force polynomial 2 (a^2 + t) (5 a^4 + 22 a^2 t + 5 t^2)
+        c.pe2 = 4.2 * a2; c.pe1 = 3.0 * a4; c.pe0 = a4 * a2 / 3.0;
+        c.pf2 = 54.0 * a2; c.pf1 = 54.0 * a4; c.pf0 = 10.0 * a4 * a2;
+        c.S = p.a_1 + p.a_2;
+        c.D = p.a_1 - p.a_2;
+        c.k0 = p.a_1 * p.a_2;
+        c.rep = p.A * s6 / 37800.0;
         c.e_cut = 0.0;
         if (energy_shift && p.A != 0.0)
             {
             double dummy;
-            if (c.kind == 0)
-                c.e_cut = solvent_solvent<false>(c, dummy, rcutsq);
-            else if (c.kind == 2)
-                c.e_cut = colloid_colloid<false>(c, dummy, rcutsq);
-            else
-                c.e_cut = colloid_solvent<false>(c, dummy, rcutsq);
+            c.e_cut = branch(c, false, dummy, rcutsq);
             }
         return c;
         }
@@ -374,14 +402,7 @@ struct EvalColloid
         pair_eng = 0.0;
         if (rsq < c.rcutsq)
             {
-            double e;
-            if (c.kind == 0)
-                e = solvent_solvent<true>(c, force_divr, rsq);
-            else if (c.kind == 2)
-                e = colloid_colloid<true>(c, force_divr, rsq);
-            else
-                e = colloid_solvent<true>(c, force_divr, rsq);
-            pair_eng = e - c.e_cut;
+            pair_eng = branch(c, true, force_divr, rsq) - c.e_cut;
             return true;
             }
         return false;
@@ -396,6 +417,10 @@ struct EvalDPDConservative
     {
     typedef azp_dpd_params Params;
     static constexpr bool kSplitEnergy = false;
+#ifndef AZP_TW_DPDC
+#define AZP_TW_DPDC 4
+#endif
+    static constexpr int kTileWaves = AZP_TW_DPDC; // waves per SIMD of the tile kernel (register budget)
     struct Coeff
         {
         double rcutsq, A, gamma, half_s, rcut, rcutinv;
@@ -417,8 +442,8 @@ struct EvalDPDConservative
         pair_eng = 0.0;
         if (rsq < c.rcutsq)
             {
-            const double rinv = 1.0 / sqrt(rsq);
-            const double r = 1.0 / rinv;
+            const double rinv = fast_rsqrt(rsq);
+            const double r = rsq * rinv;
             force_divr = c.A * (rinv - c.rcutinv);
             pair_eng = c.A * (c.rcut - r) - 0.5 * c.A * c.rcutinv * (c.rcutsq - rsq);
             return true;

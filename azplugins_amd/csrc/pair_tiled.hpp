@@ -384,7 +384,7 @@ __device__ __forceinline__ void tiled_loop(const TiledKArgs& a, const char* bx, 
     }
 
 template<class E, int TPP, int CAP, bool VIRIAL, bool SINGLE, bool XPLOR>
-__global__ void __launch_bounds__(256, AZP_TILED_WAVES_PER_SIMD) pair_forces_tiled_kernel(const TiledKArgs a, const typename E::Params* __restrict__ params)
+__global__ void __launch_bounds__(256, E::kTileWaves) pair_forces_tiled_kernel(const TiledKArgs a, const typename E::Params* __restrict__ params)
     {
     typedef typename E::Coeff Coeff;
     constexpr int TB = 256 / TPP;
