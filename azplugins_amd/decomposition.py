@@ -285,11 +285,23 @@ def rank_simulation(cfg, decomp, rank, device, seed=1):
     tag = cfg["tag"][mine] if "tag" in cfg else mine.astype(np.uint32)
     snap = Snapshot.from_arrays(xyz[mine], cfg["L"], tag=tag, velocity=cfg["vel"][mine] if "vel" in cfg else None,
                                 orientation=cfg["orientation"][mine] if "orientation" in cfg else None)
+    if "inertia" in cfg:
+        snap.particles.moment_inertia[:] = cfg["inertia"][mine]
+    if "angmom" in cfg:
+        snap.particles.angmom[:] = cfg["angmom"][mine]
     sim = Simulation(device=device, seed=seed)
     st = sim.create_state_from_snapshot(snap)
-    arrays = dict(pos=st.pos, vel=st.vel, orientation=st.orientation, tag=st.tag, image=st.image)
+    arrays = dict(pos=st.pos, vel=st.vel, orientation=st.orientation, tag=st.tag, image=st.image, angmom=st.angmom, inertia=st.inertia)
     dom = DeviceDomain(decomp, rank, arrays, density=xyz.shape[0] / float(np.prod(decomp.L)))
     dom.rebuild()
+    if cfg.get("bonds") is not None and len(cfg["bonds"]):
+        # the topology by tag, replicated (tags = indices of the global configuration unless cfg carries its own)
+        gtag = np.asarray(cfg["tag"], dtype=np.int64) if "tag" in cfg else np.arange(xyz.shape[0], dtype=np.int64)
+        b = np.asarray(cfg["bonds"], dtype=np.int64).reshape(-1, 2)
+        st.N, st.n_ghost = dom.N_local, dom.n_ghost
+        for n in dom.names:
+            setattr(st, n, dom.arrays[n])
+        st.set_global_bonds(gtag[b], cfg.get("bond_typeid", np.zeros(b.shape[0], dtype=np.uint32)), cfg.get("bond_types", ("A-A",)))
     sim.attach_domain(dom)
     return sim, dom
 

@@ -27,14 +27,15 @@ import numpy as np
 
 from .decomposition import Decomposition
 
-_ROW = {"pos": 4, "vel": 4, "orientation": 4, "tag": 1, "image": 3}
+_ROW = {"pos": 4, "vel": 4, "orientation": 4, "tag": 1, "image": 3, "angmom": 4, "inertia": 3}
+_ALL = ("pos", "vel", "orientation", "tag", "image", "angmom", "inertia")
 
 
 class DeviceDomain:
     def __init__(self, decomp, rank, arrays, group=None, density=None):
         """``arrays``: this rank's LOCAL particles, no ghosts -- ``pos`` (n, 4) float64 is
-        required; ``vel``, ``orientation`` (n, 4) float64, ``tag`` (n,) int32, ``image``
-        (n, 3) int32 travel with the particles when present. Call ``rebuild()`` next."""
+        required; ``vel``, ``orientation``, ``angmom`` (n, 4) float64, ``inertia`` (n, 3) float64, ``tag`` (n,)
+        int32, ``image`` (n, 3) int32 travel with the particles when present. Call ``rebuild()`` next."""
         import torch
 
         assert isinstance(decomp, Decomposition)
@@ -42,7 +43,7 @@ class DeviceDomain:
         self.rank = int(rank)
         self.world = decomp.world
         self.group = group
-        self.names = [n for n in ("pos", "vel", "orientation", "tag", "image") if n in arrays]
+        self.names = [n for n in _ALL if n in arrays]
         assert "pos" in self.names
         self.arrays = {n: arrays[n] for n in self.names}
         self.device = self.arrays["pos"].device
@@ -238,7 +239,8 @@ class DeviceDomain:
             self.arrays[n] = torch.cat([a, ghost], dim=0).contiguous()
         self._bufs = {}
         self.num_rebuilds += 1
-        self.exchange([n for n in self.names if n != "image"])
+        # (image flags and the rotational state are the owner's business: they migrate, ghosts do not need them)
+        self.exchange([n for n in self.names if n not in ("image", "angmom", "inertia")])
         return self.arrays
 
     # -- per-step exchange -------------------------------------------------------
@@ -334,9 +336,9 @@ class DeviceDomain:
         state.n_ghost = self.n_ghost
         for n in self.names:
             setattr(state, n, self.arrays[n])
-        if "image" not in self.names:
-            import torch
-
-            state.image = torch.zeros((state.n_max, 3), dtype=torch.int32, device=self.device)
+        # (Simulation.attach_domain insists on every array the integrator and the forces use being in self.names:
+        # an array that does not migrate would keep its old size and order)
+        if getattr(state, "bond_tags", None) is not None:
+            state.relocalize_bonds()  # bond table and exclusions by local index: every index changed
         state.position_generation += 1
         state.order_generation = getattr(state, "order_generation", 0) + 1  # every index changed: the list must be rebuilt

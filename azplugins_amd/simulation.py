@@ -74,9 +74,22 @@ class Simulation:
         any rank's distance check asks for a neighbor-list rebuild, all ranks migrate their
         particles and re-select their ghosts first (HOOMD: Communicator::migrateParticles /
         exchangeGhosts ahead of NeighborList::compute)."""
-        if self.state.bond_group.shape[0]:
-            raise _lib.AzpError("attach_domain: bonded systems are not supported in decomposed runs yet (the bond table "
-                                "holds local indices and does not migrate)")
+        if self.state.bond_group.shape[0] and self.state.bond_tags is None:
+            raise _lib.AzpError("attach_domain: a bonded system needs its topology by tag (State.set_global_bonds) -- the "
+                                "index-based bond table of a single-domain state does not survive a migration")
+        # every per-particle array that the integrator or a force touches must migrate with the particles
+        # (an array left behind keeps its old size and order while N changes under it)
+        need = ["pos", "vel", "tag", "image"]
+        integ = self.operations.integrator
+        if integ is not None:
+            for f in integ.forces:
+                need += [n for n in getattr(f, "_halo_fields", ()) if n not in need]
+            if getattr(integ, "integrate_rotational_dof", False):
+                need += ["orientation", "angmom", "inertia"]
+        missing = [n for n in need if n not in domain.names]
+        if missing:
+            raise _lib.AzpError("attach_domain: the domain does not carry %s (DeviceDomain(arrays=...) must hold every array "
+                                "the integrator and the forces use)" % ", ".join(missing))
         self.domain = domain
         domain.attach_state(self.state)
         self.operations.tuners.clear()  # the domain keeps its own interior | boundary | ghost order
@@ -134,6 +147,18 @@ class Simulation:
 
         st = self.state
         forces = self.operations.integrator.forces
+        if self.domain is not None:
+            # decomposed runs: a neighbor-list rebuild migrates particles (N and every index change). Bring every list
+            # up to date BEFORE any force buffer is sized or summed, so that all forces of this step see one order
+            seen = []
+            for f in forces:
+                nl = getattr(f, "nlist", None)
+                if nl is not None and all(nl is not s for s in seen):
+                    seen.append(nl)
+                    nl.compute(st)
+            if len(seen) > 1:
+                raise _lib.AzpError("decomposed runs support one neighbor list (a second list's rebuild would migrate "
+                                    "particles under the first)")
         if len(forces) == 1:
             # a single force: its own array is the net force (no 32 MB zero + add per step)
             forces[0].compute(self.timestep)
@@ -170,8 +195,9 @@ class Simulation:
 
         rot = None
         if integ.integrate_rotational_dof:
-            if self.domain is not None:
-                raise _lib.AzpError("integrate_rotational_dof is not supported in domain-decomposed runs yet")
+            if self.domain is not None and not all(n in self.domain.names for n in ("orientation", "angmom", "inertia")):
+                raise _lib.AzpError("integrate_rotational_dof in a decomposed run: the domain must carry orientation, angmom "
+                                    "and inertia (they migrate with the particles)")
             rot = _lib.NVERotArgs()
             rot.dt = integ.dt
 

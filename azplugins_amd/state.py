@@ -183,6 +183,26 @@ def lattice_snapshot(particle_types=("A",), n=10, a=0.6):
     return s
 
 
+def localize_bonds(tag, n_local, bond_tags, bond_typeid):
+    """The bonds of a global topology (pairs of particle tags) that one rank of a decomposed run evaluates, as index
+    pairs over its rows (``tag``: the tags of its local rows [0, n_local) followed by its ghost rows): every bond
+    with at least one LOCAL member. Returns (bond_group uint32 (n, 2), typeid)."""
+    tag = np.asarray(tag, dtype=np.int64)
+    bond_tags = np.asarray(bond_tags, dtype=np.int64).reshape(-1, 2)
+    n_glob = int(max(bond_tags.max() + 1 if bond_tags.size else 0, tag.max() + 1 if tag.size else 0))
+    rtag = np.full(n_glob + 1, -1, dtype=np.int64)
+    # (a particle can sit on a rank more than once: as a local and as its own periodic ghost; the lowest row wins
+    # -- local before ghost -- and bonds are evaluated with the minimum image)
+    rtag[tag[::-1]] = np.arange(tag.size - 1, -1, -1)
+    ia, ib = rtag[bond_tags[:, 0]], rtag[bond_tags[:, 1]]
+    mine = ((ia >= 0) & (ia < n_local)) | ((ib >= 0) & (ib < n_local))
+    if np.any(mine & ((ia < 0) | (ib < 0))):
+        raise _lib.AzpError("a bonded partner of a local particle is neither local nor a ghost on this rank: the ghost "
+                            "shell (r_cut + buffer) is narrower than a bond")
+    group = np.stack([ia[mine], ib[mine]], axis=1).astype(np.uint32).reshape(-1, 2)
+    return group, np.asarray(bond_typeid, dtype=np.uint32)[mine]
+
+
 class State:
     """Device-resident particle data (HOOMD ``ParticleData`` + ``BondData``)."""
 
@@ -218,6 +238,10 @@ class State:
         self.bond_group = np.ascontiguousarray(b.group, dtype=np.uint32).reshape(-1, 2)
         self.bond_typeid = np.ascontiguousarray(b.typeid, dtype=np.uint32)
         self._bond_table = None
+        # decomposed runs (set_global_bonds): the whole topology by particle TAG, replicated on every rank; the
+        # index-based table above is rebuilt from it whenever particles migrate (relocalize_bonds)
+        self.bond_tags = None
+        self.bond_tags_typeid = None
         self.position_generation = 0  # bumped whenever positions change
 
     @property
@@ -227,6 +251,23 @@ class State:
     @property
     def typeid_host(self):
         return self.pos[: self.N, 3].cpu().numpy().view(np.int64).astype(np.int64) & 0xFFFFFFFF
+
+    def set_global_bonds(self, bond_tags, bond_typeid, bond_types):
+        """Domain-decomposed runs: the bonds of the WHOLE system as pairs of particle tags (replicated on every
+        rank; HOOMD's BondData migrates its groups with their members, a static topology of 12 B per bond can simply
+        be everywhere). ``relocalize_bonds`` turns it into this rank's index-based table."""
+        self.bond_tags = np.ascontiguousarray(bond_tags, dtype=np.int64).reshape(-1, 2)
+        self.bond_tags_typeid = np.ascontiguousarray(bond_typeid, dtype=np.uint32)
+        self.bond_types = list(bond_types)
+        self.relocalize_bonds()
+
+    def relocalize_bonds(self):
+        """(Re)build ``bond_group`` -- index pairs over local + ghost rows -- from the tags now on this rank: every
+        bond with at least one LOCAL member (a bond is evaluated by the rank(s) owning a member); its
+        partner must be on the rank, as a local or a ghost (the ghost shell is at least one bond length wide)."""
+        tag = self.tag[: self.n_max].cpu().numpy().view(np.uint32).astype(np.int64)
+        self.bond_group, self.bond_typeid = localize_bonds(tag, self.N, self.bond_tags, self.bond_tags_typeid)
+        self._bond_table = None
 
     def bond_table(self):
         """HOOMD's per-particle GPU bond table (``BondData::getGPUTable``):
@@ -239,8 +280,9 @@ class State:
             g = self.bond_group
             nb = np.zeros(N, dtype=np.uint32)
             if g.shape[0]:
-                np.add.at(nb, g[:, 0], 1)
-                np.add.at(nb, g[:, 1], 1)
+                # (decomposed runs: a member that is a ghost here gets its row on its owner's rank)
+                np.add.at(nb, g[g[:, 0] < N, 0], 1)
+                np.add.at(nb, g[g[:, 1] < N, 1], 1)
             width = int(nb.max()) if N and g.shape[0] else 0
             width = max(width, 1)
             table = np.zeros((width, N, 2), dtype=np.uint32)
@@ -248,8 +290,10 @@ class State:
             fill = np.zeros(N, dtype=np.int64)
             for which in (0, 1):
                 # vectorised fill, one pass per member slot, stable in bond order
-                members = g[:, which].astype(np.int64)
-                partner = g[:, 1 - which]
+                local = g[:, which] < N
+                members = g[local, which].astype(np.int64)
+                partner = g[local, 1 - which]
+                btype = self.bond_typeid[local]
                 order = np.argsort(members, kind="stable")
                 m_sorted = members[order]
                 if m_sorted.size:
@@ -257,7 +301,7 @@ class State:
                     rank = np.arange(m_sorted.size) - np.repeat(start, np.diff(np.r_[start, m_sorted.size]))
                     slot = fill[m_sorted] + rank
                     table[slot, m_sorted, 0] = partner[order]
-                    table[slot, m_sorted, 1] = self.bond_typeid[order]
+                    table[slot, m_sorted, 1] = btype[order]
                     bpos[slot, m_sorted] = which
                     np.add.at(fill, members, 1)
             self._bond_table = dict(

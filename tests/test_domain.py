@@ -41,6 +41,10 @@ def _system(kind, world):
         # lattice planes sit half a spacing from the slab faces: shift them next to the faces so that
         # the drift carries particles across
         cfg["xyz"] = syn.wrap(cfg["xyz"] + np.array([0.0, 0.0, 0.45]), cfg["L"])
+    elif kind == "chains":
+        # linear chains of 8 beads along x (C3's topology at reduced size): bonds cross the rank faces
+        cfg = syn.config_chains(16, 12, 12, 8)
+        cfg["r_cut"] = 2.5
     else:
         cfg = syn.config_plj_sc(12 if world <= 4 else 16)
         cfg["r_cut"] = 2.5
@@ -62,6 +66,16 @@ def _positions(cfg, step):
 
 
 def _forces(oracle, kind, cfg, pos, vel, q, tag, box, nl, N, step):
+    if kind == "chains":
+        # DoubleWell bonds (row A8 / A9): the bonds this rank evaluates, by local index (azplugins_amd.state.localize_bonds),
+        # forces of the local rows only -- a ghost member's share belongs to its owner's evaluation of the same bond
+        from azplugins_amd.state import localize_bonds
+
+        group, typeid = localize_bonds(tag.astype(np.int64), N, cfg["bonds"], np.zeros(len(cfg["bonds"]), dtype=np.uint32))
+        p = oracle.pack_bond_params("DoubleWell", cfg["bond_params"])
+        f, bad = oracle.bond_forces("DoubleWell", pos, box, group, typeid, p)
+        assert bad == 0
+        return f[:N]
     if kind == "dpd":
         p = oracle.pack_pair_params("DPDGeneralWeight", cfg["params"])
         return oracle.dpd_forces(pos, vel, tag, box, nl, p, cfg["r_cut"], 1.0, 0.01, 7, step, N=N)
@@ -144,7 +158,7 @@ def _worker(rank, world, port, out_dir, kind):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,world", [("plj", 2), ("plj", 4), ("plj", 8), ("dpd", 2), ("dpd", 8), ("tpm", 4)])
+@pytest.mark.parametrize("kind,world", [("plj", 2), ("plj", 4), ("plj", 8), ("dpd", 2), ("dpd", 8), ("tpm", 4), ("chains", 2), ("chains", 4)])
 def test_migration_ghosts_and_packed_exchange_gloo(kind, world, tmp_path, oracle):
     import torch.multiprocessing as mp
 

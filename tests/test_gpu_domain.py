@@ -4,8 +4,10 @@ Simulation.run with a DeviceDomain attached -- per-step packed halo exchange, co
 rebuild decision, particle migration and ghost re-selection at every neighbor-list rebuild,
 tile plan recompiled after each -- and must end where a single-domain run of the same
 initial state ends (positions and velocities by tag). Covers the PerturbedLJ tile kernel
-with its displacement bound on moving ghosts, and the DPD thermostat (both owners of a
-cross-rank pair must draw the same random number)."""
+with its displacement bound on moving ghosts, the DPD thermostat (both owners of a
+cross-rank pair must draw the same random number), TwoPatchMorse with rotational degrees of freedom
+(orientations, angular momenta and moments of inertia migrate) and a bonded system (PerturbedLJ +
+DoubleWell: two forces on one list, the bond table rebuilt from the topology by tag after every migration)."""
 
 import os
 import socket
@@ -30,6 +32,27 @@ def _config(kind):
     if kind == "dpd":
         cfg = syn.config_dpd(8000)
         cfg["steps"] = 30
+    elif kind == "tpm":
+        # patchy colloids with rotational degrees of freedom (orientation, angular momentum and moments of inertia
+        # migrate with the particles): 1 x 1 x 2 slabs
+        cfg = syn.config_tpm(10, 10, 20)
+        n = cfg["xyz"].shape[0]
+        tag = np.arange(n, dtype=np.uint64)
+        v = np.stack([syn.normal(61, tag, c) for c in range(3)], axis=1) * np.sqrt(2.0)
+        cfg["vel"] = v - v.mean(axis=0)
+        cfg["inertia"] = np.tile(np.array([0.1, 0.12, 0.14]), (n, 1))
+        cfg["steps"] = 40
+        cfg["dt"] = 0.004
+    elif kind == "chains":
+        # PerturbedLJ + DoubleWell bonds on chains of 8 (two forces, one list; bonds cross the rank face)
+        cfg = syn.config_chains(16, 16, 16, 8)
+        n = cfg["xyz"].shape[0]
+        tag = np.arange(n, dtype=np.uint64)
+        v = np.stack([syn.normal(71, tag, c) for c in range(3)], axis=1) * np.sqrt(1.2)
+        cfg["vel"] = v - v.mean(axis=0)
+        cfg["r_cut"], cfg["r_buff"] = 2.5, 0.4
+        cfg["steps"] = 60
+        cfg["dt"] = 0.004
     else:
         cfg = syn.config_plj_sc(16)
         n = cfg["xyz"].shape[0]
@@ -44,10 +67,22 @@ def _config(kind):
 def _potential(azp, kind, cfg, nl):
     if kind == "dpd":
         pot = azp.pair.DPDGeneralWeight(nlist=nl, kT=cfg["kT"], default_r_cut=cfg["r_cut"])
+    elif kind == "tpm":
+        pot = azp.pair.TwoPatchMorse(nlist=nl, default_r_cut=cfg["r_cut"], mode="shift")
     else:
         pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=cfg["r_cut"], mode="shift")
     pot.params[("A", "A")] = cfg["params"]
     return pot
+
+
+def _integrator(azp, kind, cfg, nl):
+    pot = _potential(azp, kind, cfg, nl)
+    forces = [pot]
+    if kind == "chains":
+        dw = azp.bond.DoubleWell()
+        dw.params["A-A"] = cfg["bond_params"]
+        forces.append(dw)
+    return pot, azp.Integrator(dt=cfg["dt"], forces=forces, methods=[azp.ConstantVolume()], integrate_rotational_dof=(kind == "tpm"))
 
 
 def _worker(rank, world, port, out_dir, kind):
@@ -65,20 +100,20 @@ def _worker(rank, world, port, out_dir, kind):
     dec = dd.Decomposition(cfg["L"], world, cfg["r_cut"] + cfg["r_buff"])
     sim, dom = dd.rank_simulation(cfg, dec, rank, "cuda:0", seed=cfg.get("seed", 1))
     nl = azp.nlist.Cell(buffer=cfg["r_buff"])
-    pot = _potential(azp, kind, cfg, nl)
-    sim.operations.integrator = azp.Integrator(dt=cfg["dt"], forces=[pot], methods=[azp.ConstantVolume()])
+    pot, sim.operations.integrator = _integrator(azp, kind, cfg, nl)
     sim.run(cfg["steps"])
     torch.cuda.synchronize()
     st = sim.state
     N = st.N
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), tag=st.tag[:N].cpu().numpy().view(np.uint32), pos=st.pos[:N, :3].cpu().numpy(),
-             vel=st.vel[:N, :3].cpu().numpy(), rebuilds=np.array([dom.num_rebuilds]), builds=np.array([nl.num_builds]),
+             vel=st.vel[:N, :3].cpu().numpy(), q=st.orientation[:N].cpu().numpy(), angmom=st.angmom[:N].cpu().numpy(),
+             rebuilds=np.array([dom.num_rebuilds]), builds=np.array([nl.num_builds]),
              plan_valid=np.array([(pot.plan_info or {}).get("valid", -1)]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["plj", "dpd"])
+@pytest.mark.parametrize("kind", ["plj", "dpd", "tpm", "chains"])
 def test_decomposed_md_run_matches_single_domain(kind, tmp_path):
     import torch
     import torch.multiprocessing as mp
@@ -90,10 +125,13 @@ def test_decomposed_md_run_matches_single_domain(kind, tmp_path):
     cfg = _config(kind)
     n = cfg["xyz"].shape[0]
     sim = azp.Simulation(device="cuda:0", seed=cfg.get("seed", 1))
-    sim.create_state_from_snapshot(azp.Snapshot.from_arrays(cfg["xyz"], cfg["L"], tag=cfg.get("tag"), velocity=cfg["vel"]))
+    snap = azp.Snapshot.from_arrays(cfg["xyz"], cfg["L"], tag=cfg.get("tag"), velocity=cfg["vel"], orientation=cfg.get("orientation"),
+                                    bonds=cfg.get("bonds") if kind == "chains" else None)
+    if "inertia" in cfg:
+        snap.particles.moment_inertia[:] = cfg["inertia"]
+    sim.create_state_from_snapshot(snap)
     nl = azp.nlist.Cell(buffer=cfg["r_buff"])
-    pot = _potential(azp, kind, cfg, nl)
-    sim.operations.integrator = azp.Integrator(dt=cfg["dt"], forces=[pot], methods=[azp.ConstantVolume()])
+    pot, sim.operations.integrator = _integrator(azp, kind, cfg, nl)
     sim.operations.tuners.clear()
     sim.run(cfg["steps"])
     torch.cuda.synchronize()
@@ -102,15 +140,23 @@ def test_decomposed_md_run_matches_single_domain(kind, tmp_path):
     ref_vel = np.zeros((n, 3))
     ref_pos[tag] = sim.state.pos[:, :3].cpu().numpy()
     ref_vel[tag] = sim.state.vel[:, :3].cpu().numpy()
+    ref_q = np.zeros((n, 4))
+    ref_p = np.zeros((n, 4))
+    ref_q[tag] = sim.state.orientation.cpu().numpy()
+    ref_p[tag] = sim.state.angmom.cpu().numpy()
     got_pos = np.full((n, 3), np.nan)
     got_vel = np.full((n, 3), np.nan)
+    got_q = np.full((n, 4), np.nan)
+    got_p = np.full((n, 4), np.nan)
     rebuilds = []
     for r in range(world):
         d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
         got_pos[d["tag"].astype(np.int64)] = d["pos"]
         got_vel[d["tag"].astype(np.int64)] = d["vel"]
+        got_q[d["tag"].astype(np.int64)] = d["q"]
+        got_p[d["tag"].astype(np.int64)] = d["angmom"]
         rebuilds.append(int(d["rebuilds"][0]))
-        if kind == "plj":
+        if kind in ("plj", "chains"):
             assert int(d["plan_valid"][0]) == 1  # the tile kernel ran on every rank
     assert min(rebuilds) >= 3, "the run must cross several neighbor-list rebuilds (with migration): %r" % rebuilds
     assert nl.num_builds >= 3
@@ -119,3 +165,8 @@ def test_decomposed_md_run_matches_single_domain(kind, tmp_path):
     dx -= L * np.round(dx / L)
     assert np.all(np.isfinite(got_pos)) and np.abs(dx).max() < 1e-9, np.abs(dx).max()
     assert np.abs(got_vel - ref_vel).max() < 1e-8 * max(1.0, np.abs(ref_vel).max())
+    if kind == "tpm":
+        # the rotational state travelled with the particles: orientations and angular momenta end where the
+        # single-domain run's end (and the momenta are not all zero: the patch torques acted)
+        assert np.abs(got_q - ref_q).max() < 1e-8 and np.abs(got_p - ref_p).max() < 1e-8 * max(1.0, np.abs(ref_p).max())
+        assert np.abs(ref_p).max() > 1e-3
