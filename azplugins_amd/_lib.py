@@ -53,6 +53,8 @@ class PairArgs(C.Structure):
         ("displacement_bound", C.c_double),
         ("d_displacement", C.c_void_p),
         ("list_generation", C.c_uint64),
+        ("d_stale_flag", C.c_void_p),
+        ("d_displacement_sq_bits", C.c_void_p),
         ("displacement_bound_extra", C.c_double),
     ]
 
@@ -231,6 +233,7 @@ SYMBOLS = {
     "azp_pair_plan_query": (C.c_int, [_VP, C.POINTER(PlanInfo)]),
     "azp_pair_plan_phase_chunks": (C.c_int, [_VP, C.POINTER(C.c_float)]),
     "azp_tuning_set": (C.c_int, [C.c_int, C.c_int]),
+    "azp_sum_forces": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), _VP, _VP]),
     "azp_pair_auto_plan_get_stats": (None, [C.POINTER(AutoPlanStats)]),
     "azp_pair_auto_plan_clear": (None, []),
     "azp_pair_forces_planned_perturbed_lennard_jones": (C.c_int, [_VP, C.POINTER(PairArgs), _VP, _VP]),

@@ -73,6 +73,7 @@ class Bond(Force):
         self._ensure_buffers()
         if self._tables is None:
             self._build_tables()
+            self._flags.zero_()  # (new parameters: the sticky "rejected" flag starts over)
         tab = st.bond_table()
         a = _lib.BondArgs()
         a.d_force = self._force.data_ptr()
@@ -89,14 +90,43 @@ class Bond(Force):
         a.n_bond_types = max(len(st.bond_types), 1)
         a.compute_virial = 1 if self.compute_virial else 0
         a.block_size = self.block_size
-        self._flags.zero_()
+        # The evaluator's "rejected its parameters" flag (HOOMD: "bond.<name>: bond out of bounds") is sticky on the
+        # device (the kernel only ever sets it) and travels to the host on a side stream behind each launch; it is
+        # LOOKED AT when the next launch is queued, by which time it has long arrived -- a readback right behind
+        # the launch would idle the GPU for a host round trip every step. check_flags() looks now.
+        self.check_flags(wait=False)
         stream = _lib.raw_stream(st.device)
         fn = getattr(_lib.lib(), self._entry)
         _lib.check(fn(C.byref(a), self._tables["params"].data_ptr(), self._flags.data_ptr(), stream), self._entry)
-        if int(self._flags.item()) != 0:
+        if getattr(self, "_flag_side", None) is None:
+            self._flag_side = torch.cuda.Stream(device=st.device)
+            self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        done = torch.cuda.Event()
+        done.record()
+        with torch.cuda.stream(self._flag_side):
+            self._flag_side.wait_event(done)
+            self._flag_host.copy_(self._flags, non_blocking=True)
+        self._flag_pending = torch.cuda.Event()
+        self._flag_pending.record(self._flag_side)
+        self._computed_generation = st.position_generation
+        if not self.defer_flag_check:
+            self.check_flags(wait=True)
+
+    defer_flag_check = False  # True inside Simulation.run: the flag of step k is examined when step k + 1 is queued
+
+    def check_flags(self, wait=True):
+        """Raise if an evaluator rejected its parameters in a launch whose flag has reached the host
+        (``wait=True``: of every launch so far)."""
+        ev = getattr(self, "_flag_pending", None)
+        if ev is None:
+            return
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        if int(self._flag_host[0]) != 0:
             # HOOMD: "bond.<name>: bond out of bounds" when the evaluator returns false
             raise _lib.AzpError("bond.%s: bond out of bounds (evaluator rejected its parameters)" % type(self).__name__)
-        self._computed_generation = st.position_generation
 
 
 class DoubleWell(Bond):

@@ -223,6 +223,52 @@ extern "C" int azp_integrate_nve_step_two_one(const azp_nve_args* args, void* st
     return azp::launch_nve<2>(args, stream);
     }
 
+// Net force of several ForceComputes in ONE pass (HOOMD: Integrator::computeNetForce sums the forces' arrays):
+// out = f[0] + f[1] + ... row by row, every array read once, the sum written once (a chain of framework
+// element-wise operations would write and re-read the 32 MB accumulator once per force).
+namespace azp
+{
+struct SumForcesArgs
+    {
+    const double* f[8];
+    double* out;
+    uint32_t n_rows, k;
+    };
+__global__ void __launch_bounds__(256) sum_forces_kernel(const SumForcesArgs a)
+    {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.n_rows)
+        return;
+    double4 v = load_scalar4(a.f[0], i);
+    for (uint32_t q = 1; q < a.k; ++q)
+        {
+        const double4 w = load_scalar4(a.f[q], i);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+    store_scalar4(a.out, i, v.x, v.y, v.z, v.w);
+    }
+} // namespace azp
+
+extern "C" int azp_sum_forces(uint32_t n_rows, uint32_t n_arrays, const double* const* d_arrays, double* d_out, void* stream)
+    {
+    using namespace azp;
+    if (!d_arrays || !d_out || n_arrays == 0 || n_arrays > 8)
+        return AZP_ERROR_INVALID_ARGUMENT;
+    if (n_rows == 0)
+        return AZP_SUCCESS;
+    SumForcesArgs a;
+    for (uint32_t q = 0; q < 8; ++q)
+        a.f[q] = (q < n_arrays) ? d_arrays[q] : nullptr;
+    for (uint32_t q = 0; q < n_arrays; ++q)
+        if (!a.f[q])
+            return AZP_ERROR_INVALID_ARGUMENT;
+    a.out = d_out;
+    a.n_rows = n_rows;
+    a.k = n_arrays;
+    hipLaunchKernelGGL(sum_forces_kernel, dim3((n_rows + 255u) / 256u), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+    }
+
 // src/PlanarBarrierEvaluator.h:50-55: H inside [lo.y, hi.y), lo / hi = box.makeCoordinates((0,0,0)) /
 // ((1,1,1)). HOOMD's makeCoordinates shears the fractional point, y += yz * z, so for a
 // triclinic box the corners sit at y = -+(Ly / 2 + yz Lz / 2).

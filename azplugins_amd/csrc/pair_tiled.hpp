@@ -76,6 +76,10 @@ struct TiledKArgs
     // displacements <= 2 x the largest one in the tile -- instead of the shells the fastest particle of the whole system
     // dictates. bound_extra is added to every entry (a plan compiled later than the positions the displacements refer to).
     const TileDyn* dyn;           // NULL: n_shells / bound above are final
+    // the same idea with the raw words of the neighbor list's distance check (azp_pair_args.d_stale_flag,
+    // d_displacement_sq_bits): leave when *dflag != 0, bound = sqrt(double(*dbits)) + bound_extra
+    const uint32_t* dflag;
+    const unsigned long long* dbits;
     const float* disp;            // n_max entries; NULL: the global bound above
     double shell_w;               // shell width of the plan
     double shell_winv;            // 1 / shell_w (0: no shells)
@@ -133,6 +137,10 @@ inline void fill_local_bound(TiledKArgs& k, const PairPlan& plan, const azp_pair
     // reference positions of d_displacement
     const bool local = args.d_displacement && args.has_displacement_bound && args.displacement_bound >= 0.0;
     k.disp = (local && tuning().local_bound != 0) ? args.d_displacement : nullptr;
+    k.dflag = (args.d_stale_flag && args.d_displacement_sq_bits) ? args.d_stale_flag : nullptr;
+    k.dbits = k.dflag ? args.d_displacement_sq_bits : nullptr;
+    if (k.dflag)
+        k.disp = nullptr; // (the per-particle displacements of a check whose result is not known yet are not either)
     k.shell_w = plan.shell_width;
     k.shell_winv = plan.shell_width > 0.0 ? 1.0 / plan.shell_width : 0.0;
     k.bound_extra = args.displacement_bound_extra > 0.0 ? args.displacement_bound_extra : 0.0;
@@ -416,6 +424,8 @@ __global__ void __launch_bounds__(256, E::kTileWaves) pair_forces_tiled_kernel(c
         return;
     if (a.dyn && a.dyn->stale) // speculative launch on a plan that turned out stale (uniform: whole grid leaves)
         return;
+    if (a.dflag && *a.dflag)   // ... or whose list has to be rebuilt first (the distance check said so)
+        return;
 
     Coeff c0;
     double ronsq0 = 0.0;
@@ -581,6 +591,13 @@ __global__ void __launch_bounds__(256, E::kTileWaves) pair_forces_tiled_kernel(c
     // the displacement bound of this tile and the shells it has to walk
     double bound = a.dyn ? a.dyn->bound : a.bound;
     uint32_t n_shells = a.dyn ? min(a.dyn->n_shells, PLAN_SHELLS) : a.n_shells;
+    if (a.dbits)
+        {
+        bound = to_uniform(sqrt(__longlong_as_double((long long)*a.dbits)) + a.bound_extra);
+        n_shells = tile_shells_for(bound, a.shell_winv);
+        if (!(bound >= 0.0) || !(bound < 1.0e300))
+            bound = -1.0;
+        }
     if (a.disp)
         {
         const float d4 = fmaxf(fmaxf(s_dmax[0], s_dmax[1]), fmaxf(s_dmax[2], s_dmax[3]));

@@ -50,6 +50,8 @@ __global__ void __launch_bounds__(256, X::kMinWaves) xtiled_kernel(const TiledKA
         return;
     if (a.dyn && a.dyn->stale) // speculative launch on a stale plan (pair_auto.hpp)
         return;
+    if (a.dflag && *a.dflag)   // ... or on a list the distance check wants rebuilt (azp_pair_args.d_stale_flag)
+        return;
 
     Coeff c0;
     if (SINGLE)
@@ -166,6 +168,8 @@ __global__ void __launch_bounds__(256, X::kMinWaves) xtiled_kernel(const TiledKA
     const bool wide = __syncthreads_or(lane_wide); // also publishes the staged tile
     __builtin_amdgcn_s_setprio(0);
     uint32_t n_shells = a.dyn ? min(a.dyn->n_shells, PLAN_SHELLS) : a.n_shells;
+    if (a.dbits)
+        n_shells = tile_shells_for(to_uniform(sqrt(__longlong_as_double((long long)*a.dbits)) + a.bound_extra), a.shell_winv);
     if (a.disp)
         n_shells = tile_shells_for(to_uniform((double)fmaxf(fmaxf(s_dmax[0], s_dmax[1]), fmaxf(s_dmax[2], s_dmax[3])) + a.bound_extra), a.shell_winv);
 

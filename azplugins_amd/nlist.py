@@ -131,7 +131,9 @@ class Cell(NeighborList):
         if not force and self.built:
             if self._built_generation == state.position_generation:
                 return
-            moved = self._moved_too_far(state)
+            v = getattr(self, "_verdict", None)
+            # (a caller that queued its kernel behind the check -- Pair._compute_speculative -- has the verdict already)
+            moved = v[1] if (v is not None and v[0] == state.position_generation) else self._moved_too_far(state)
             if self.reduce_flag is not None:
                 moved = bool(self.reduce_flag(moved))
             if not moved:
@@ -145,12 +147,21 @@ class Cell(NeighborList):
     def _moved_too_far(self, state):
         """One kernel + an 16-byte readback (HOOMD's distance check); also records the
         largest displacement since the build (``displacement_bound``)."""
+        return self.end_check(self.begin_check(state))
+
+    def begin_check(self, state):
+        """Queue the distance check on the current stream and its 16-byte readback on a side stream (ordered after
+        the check alone). Returns a token for ``end_check``; ``token["flag_ptr"]`` / ``token["bits_ptr"]`` are the
+        device words a force kernel queued right behind the check can read (azp_pair_args.d_stale_flag,
+        d_displacement_sq_bits), so that the host's wait for the result does not idle the GPU."""
         import torch
 
         # [flag, max |dx|^2 bits] per check, a ring of 64 rows zeroed once per 64 checks (not a fill kernel per step)
         if getattr(self, "_flag", None) is None or self._flag.device != state.pos.device:
             self._flag = torch.zeros((64, 2), dtype=torch.int64, device=state.pos.device)
             self._flag_i = 0
+            self._side = torch.cuda.Stream(device=state.pos.device)
+            self._host_row = torch.zeros(2, dtype=torch.int64).pin_memory()
         if self._flag_i == 64:
             self._flag.zero_()
             self._flag_i = 0
@@ -158,7 +169,7 @@ class Cell(NeighborList):
         self._flag_i += 1
         box = state.box.to_c()
         stream = _lib.raw_stream(state.device)
-        # every particle's own displacement next to the maximum: the tile kernels take the maximum over what a
+        # every particle's own displacement next to the maximum: the tile kernels can take the maximum over what a
         # tile stages (azp_pair_args.d_displacement) instead of the global one
         if getattr(self, "_disp_arr", None) is None or self._disp_arr.shape[0] != state.n_max or self._disp_arr.device != state.pos.device:
             self._disp_arr = torch.zeros(state.n_max, dtype=torch.float32, device=state.pos.device)
@@ -166,10 +177,21 @@ class Cell(NeighborList):
                                                       C.byref(box), (0.5 * self.buffer) ** 2, row.data_ptr(),
                                                       row.data_ptr() + 8, self._disp_arr.data_ptr(), stream),
                    "azp_nlist_displacements")
-        flag, bits = row.tolist()
+        done = torch.cuda.Event()
+        done.record()
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(done)
+            self._host_row.copy_(row, non_blocking=True)
+        return dict(flag_ptr=row.data_ptr(), bits_ptr=row.data_ptr() + 8, generation=state.position_generation, row=row)
+
+    def end_check(self, token):
+        """Wait for the check of ``begin_check`` (not for anything queued after it); True: rebuild."""
+        self._side.synchronize()
+        flag, bits = self._host_row.tolist()
         self._disp = float(np.sqrt(np.array([bits], dtype=np.int64).view(np.float64)[0]))
-        self._disp_generation = state.position_generation
-        self._disp_arr_generation = state.position_generation
+        self._disp_generation = token["generation"]
+        self._disp_arr_generation = token["generation"]
+        self._verdict = (token["generation"], bool(flag))
         return bool(flag)
 
     def displacement_bound(self, state):

@@ -48,6 +48,8 @@ class Pair(Force):
         self.use_local_displacement = False
         self.plan_bank_order = None     # None: bank-aware rows only for long-lived lists (below); True / False: always / never
         self.use_fused_plan = True      # sole consumer of its list: compile the plan straight from the binned particles
+        self.use_speculative_launch = True  # queue the force kernel behind the list's distance check (_compute_speculative)
+        self._plan_valid = False
         self._plan_ids = None
         self._plan = None
         self._plan_builds = None
@@ -241,6 +243,8 @@ class Pair(Force):
 
         self._require()
         st = self._state
+        if particle_range is None and self._compute_speculative(timestep):
+            return
         self.nlist.compute(st)
         self._ensure_buffers()  # after the list: a rebuild of a decomposed run migrates particles
         if self._tables is None:
@@ -250,6 +254,40 @@ class Pair(Force):
         self._launch(stream, timestep)
         self._range = None
         self._computed_generation = st.position_generation
+
+    def _compute_speculative(self, timestep):
+        """The common MD step -- the list was built earlier, the particles have moved, the plan is current: queue the
+        neighbor list's distance check AND the force kernel behind it before asking for the check's result. The
+        kernel reads the displacement bound from the check's device words and leaves at once if the check asks for
+        a rebuild (azp_pair_args.d_stale_flag); the host then waits for the check alone while the GPU is already
+        computing forces, instead of idling it for a readback and a launch every step. Returns False when the
+        ordinary path has to run (first call, rebuild, no plan, decomposed run)."""
+        nl, st = self.nlist, self._state
+        if not (self.use_speculative_launch and self.use_plan and self._planned_entry is not None and self.use_displacement_bound
+                and self._plan is not None and self._tables is not None and hasattr(nl, "begin_check")):
+            return False
+        if not (nl.built and nl.reduce_flag is None and nl.before_rebuild is None and self._plan_builds == self._plan_key()
+                and nl._built_consumer_version == nl._consumer_version and nl._built_generation != st.position_generation
+                and getattr(st, "order_generation", 0) == getattr(nl, "_order_generation", 0)
+                and getattr(self, "_plan_disp0", None) is not None and self._force.shape[0] == st.N):
+            return False
+        if not self._plan_valid:
+            return False
+        token = nl.begin_check(st)
+        a = self._pair_args(for_launch=True)
+        a.has_displacement_bound, a.displacement_bound, a.d_displacement = 0, 0.0, None
+        a.d_stale_flag, a.d_displacement_sq_bits = token["flag_ptr"], token["bits_ptr"]
+        a.displacement_bound_extra = self._plan_disp0
+        args = self._wrap_args(a, timestep)
+        stream = _lib.raw_stream(st.device)
+        fn = getattr(_lib.lib(), self._planned_entry)
+        _lib.check(fn(self._plan.handle, C.byref(args), self._tables["params"].data_ptr(), stream), self._planned_entry)
+        self._calls_since_plan = getattr(self, "_calls_since_plan", 0) + 1
+        if nl.end_check(token):
+            return False  # rebuild: the kernel left without writing; the ordinary path takes over (it has the verdict)
+        nl._built_generation = st.position_generation
+        self._computed_generation = st.position_generation
+        return True
 
     def _prepare_plan(self, a, stream):
         """Compile the tile plan when the neighbor list was rebuilt since the last compile and
@@ -272,6 +310,7 @@ class Pair(Force):
                     break
                 cap = (int(info["max_row"] * 1.06) + 4 + 7) // 8 * 8  # a row overflowed: longer rows (HOOMD's protocol)
             a.range_first, a.range_count = first, count
+            self._plan_valid = bool(info["valid"])
             if info["valid"]:
                 nl._fused_failures = 0
                 nl._plan_row_capacity = max((int(info["max_row"] * 1.06) + 4 + 7) // 8 * 8, 32)
@@ -308,6 +347,7 @@ class Pair(Force):
             self._calls_since_plan = 0
             self._plan.build(a, stream)
             a.range_first, a.range_count = first, count
+            self._plan_valid = bool(self._plan.info()["valid"])
             self._plan_builds = key
             self._plan_disp0 = self.nlist.displacement_bound(self._state)
             # this launch sees exactly the positions the plan was built from

@@ -63,8 +63,9 @@ class ParticleSorter:
         if st.bond_group.shape[0]:
             inv = torch.empty(N, dtype=torch.int64, device=st.device)
             inv[order] = torch.arange(N, dtype=torch.int64, device=st.device)
-            inv_h = inv.cpu().numpy()
-            st.bond_group = inv_h[st.bond_group.astype(np.int64)].astype(np.uint32)
+            # (the 10^6-entry lookup on the device: numpy took 40 ms for C3's bonds)
+            g = torch.from_numpy(st.bond_group.astype(np.int64)).to(st.device)
+            st.bond_group = inv[g].to(torch.int32).cpu().numpy().view(np.uint32).reshape(-1, 2)
             st._bond_table = None
         st.position_generation += 1
         st.order_generation = getattr(st, "order_generation", 0) + 1

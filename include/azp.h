@@ -180,6 +180,16 @@ typedef struct azp_pair_args
                                     changes whenever it rewrites the neighbor list (HOOMD: NeighborList::getNumUpdates()
                                     + 1). Non-zero: the cached plan is recompiled exactly when the number changes and the
                                     list is not fingerprinted; 0 = unknown, the list is fingerprinted at every call. */
+    const uint32_t* d_stale_flag; /* optional, read by the *_planned entry points together with the next field: the two
+                                    words azp_nlist_distance_check / azp_nlist_displacements leave in device memory
+                                    (d_flag and d_max_dist_sq_bits). The kernel then takes its displacement bound from
+                                    there AT RUN TIME (sqrt of the double whose bits are in *d_displacement_sq_bits, plus
+                                    displacement_bound_extra), and its workgroups leave at once when *d_stale_flag != 0
+                                    (some particle moved farther than the check's limit: the list has to be rebuilt and
+                                    the call repeated). A caller can so queue the force kernel right behind the check,
+                                    before the host knows its result. has_displacement_bound / displacement_bound are
+                                    ignored when these are set. */
+    const unsigned long long* d_displacement_sq_bits;
     double displacement_bound_extra; /* added to every d_displacement entry: how far any particle had moved from those
                                     reference positions when the plan was built (0 in the usual flow: plan and list are
                                     built from the same positions) */
@@ -534,6 +544,9 @@ int azp_integrate_nve_step_two(const azp_nve_args* args, void* stream);
  * velocities between the two (HOOMD calls integrateStepTwo and the next integrateStepOne back to back unless an
  * updater or analyzer is due). Same arithmetic in the same order as the two calls, one pass over the arrays. */
 int azp_integrate_nve_step_two_one(const azp_nve_args* args, void* stream);
+/* Net force of up to 8 force arrays (N x 4 each; HOOMD: Integrator::computeNetForce) in one pass:
+ * d_out[i] = d_arrays[0][i] + d_arrays[1][i] + ... (d_arrays: HOST array of n_arrays device pointers). */
+int azp_sum_forces(uint32_t n_rows, uint32_t n_arrays, const double* const* d_arrays, double* d_out, void* stream);
 
 /* Rotational degrees of freedom of the same step ("+ rotational for
  * aniso"; the reference's aniso test gives its particles a moment of inertia,

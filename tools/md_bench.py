@@ -23,17 +23,25 @@ ap.add_argument("--ncell", type=int, default=64)
 ap.add_argument("--no-plan", action="store_true")
 ap.add_argument("--sort-period", type=int, default=200, help="re-index the particles every this many steps (0 = never)")
 ap.add_argument("--curve", default="hilbert", help="particle sorter: hilbert | blocks")
+ap.add_argument("--workload", default="ns", help="ns: the north-star liquid (PerturbedLJ); c3: BASELINE configs[2], 32,768 chains of 32 beads, "
+                                                 "PerturbedLJ + DoubleWell bonds")
+ap.add_argument("--buffer", type=float, default=None, help="neighbor-list buffer r_buff (default: the workload's 0.4; HOOMD users tune it)")
 args = ap.parse_args()
 
-cfg = syn.config_north_star(args.ncell)
+cfg = syn.config_north_star(args.ncell) if args.workload == "ns" else syn.config_chains()
 N = cfg["xyz"].shape[0]
 sim = azp.Simulation(device="cuda:0", seed=1)
-sim.create_state_from_snapshot(azp.Snapshot.from_arrays(cfg["xyz"], cfg["L"]))
-nl = azp.nlist.Cell(buffer=cfg["r_buff"])
+sim.create_state_from_snapshot(azp.Snapshot.from_arrays(cfg["xyz"], cfg["L"], bonds=cfg.get("bonds") if args.workload == "c3" else None))
+nl = azp.nlist.Cell(buffer=args.buffer if args.buffer is not None else cfg["r_buff"])
 pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=cfg["r_cut"])
 pot.params[("A", "A")] = cfg["params"]
 pot.use_plan = not args.no_plan
-sim.operations.integrator = azp.Integrator(dt=args.dt, forces=[pot], methods=[azp.ConstantVolume()])
+forces = [pot]
+if args.workload == "c3":
+    dw = azp.bond.DoubleWell()
+    dw.params["A-A"] = cfg["bond_params"]
+    forces.append(dw)
+sim.operations.integrator = azp.Integrator(dt=args.dt, forces=forces, methods=[azp.ConstantVolume()])
 sim.operations.tuners.clear()
 if args.sort_period:
     sim.operations.tuners.append(azp.ParticleSorter(trigger_period=args.sort_period, curve=args.curve))
@@ -42,12 +50,12 @@ sim.thermalize_particle_momenta(args.kT, seed=7)
 sim.run(50)  # melt the lattice a little, warm the allocator
 torch.cuda.synchronize()
 b0 = nl.num_builds
-e0 = pot.energy + 0.5 * float((sim.state.vel[:N, 3] * (sim.state.vel[:N, :3] ** 2).sum(1)).sum())
+e0 = sum(f.energy for f in forces) + 0.5 * float((sim.state.vel[:N, 3] * (sim.state.vel[:N, :3] ** 2).sum(1)).sum())
 t0 = time.perf_counter()
 sim.run(args.steps)
 torch.cuda.synchronize()
 t = time.perf_counter() - t0
-e1 = pot.energy + 0.5 * float((sim.state.vel[:N, 3] * (sim.state.vel[:N, :3] ** 2).sum(1)).sum())
+e1 = sum(f.energy for f in forces) + 0.5 * float((sim.state.vel[:N, 3] * (sim.state.vel[:N, :3] ** 2).sum(1)).sum())
 builds = nl.num_builds - b0
 print("N=%d  %d steps in %.3f s: %.3f ms/step, %.3e particle-steps/s; %d neighbor-list (+plan) rebuilds = one per %.1f steps; "
       "kT=%.3f; energy drift %.2e per particle" % (N, args.steps, t, 1e3 * t / args.steps, N * args.steps / t, builds,
