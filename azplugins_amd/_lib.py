@@ -249,6 +249,7 @@ SYMBOLS = {
     "azp_bond_forces_quartic": (C.c_int, [C.POINTER(BondArgs), _VP, _VP, _VP]),
     "azp_nlist_cell_assign": (C.c_int, [C.POINTER(NlistArgs), _VP]),
     "azp_nlist_cell_bounds": (C.c_int, [C.POINTER(NlistArgs), _VP]),
+    "azp_nlist_bin": (C.c_int, [C.POINTER(NlistArgs), _VP, _VP, _VP]),
     "azp_nlist_count": (C.c_int, [C.POINTER(NlistArgs), _VP]),
     "azp_nlist_fill": (C.c_int, [C.POINTER(NlistArgs), _VP]),
     "azp_sorter_keys": (C.c_int, [C.c_uint32, _VP, C.POINTER(Box), C.POINTER(C.c_uint32), C.c_uint32, _VP, _VP]),

@@ -66,6 +66,136 @@ __global__ void __launch_bounds__(256) cell_bounds_kernel(uint32_t n_total, uint
     cell_start[c] = lo;
     }
 
+// ---- binning in one call (azp_nlist_bin): counting sort of the particles by cell, stable in the particle index ----
+// Lanes of a wave that hold the same key add to its counter with ONE atomic (consecutive particles of a spatially sorted
+// system sit in the same cell: a plain atomic per lane serialises 32-deep on one address). Returns this lane's slot
+// base + rank among the wave's lanes with that key.
+__device__ __forceinline__ uint32_t wave_aggregated_add(uint32_t* counters, uint32_t key, bool active)
+    {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t result = 0;
+    unsigned long long todo = __ballot(active);
+    while (todo)
+        {
+        const int leader = __builtin_ctzll(todo);
+        const uint32_t k0 = (uint32_t)__shfl((int)key, leader, 64);
+        const unsigned long long same = __ballot(active && key == k0) & todo;
+        uint32_t base = 0;
+        if ((int)lane == leader)
+            base = atomicAdd(&counters[k0], (uint32_t)__popcll(same));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (active && key == k0)
+            result = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+        }
+    return result;
+    }
+
+__global__ void __launch_bounds__(256) bin_assign_count_kernel(uint32_t n_total, const double* __restrict__ pos, GridDev g,
+                                                               uint32_t* __restrict__ cell_of, uint32_t* __restrict__ count)
+    {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < n_total;
+    uint32_t c = 0;
+    if (active)
+        {
+        const double3 p = load_scalar3_of4(pos, i);
+        const int cx = cell_coord(g, 0, p.x), cy = cell_coord(g, 1, p.y), cz = cell_coord(g, 2, p.z);
+        c = (uint32_t)((cz * g.dim[1] + cy) * g.dim[0] + cx);
+        cell_of[i] = c;
+        }
+    (void)wave_aggregated_add(count, c, active);
+    }
+
+// exclusive scan of ncell counts into cell_start[0 .. ncell] by ONE workgroup of 1,024 threads, 4,096 counters per
+// trip (four per thread, wave scans by shuffles, one LDS hop for the 16 wave totals; the carry in a register);
+// count[] is left holding the cell starts too (the scatter's cursors)
+__global__ void __launch_bounds__(1024) bin_scan_kernel(uint32_t ncell, uint32_t* __restrict__ count, uint32_t* __restrict__ cell_start)
+    {
+    __shared__ uint32_t s_wave[16];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    uint32_t carry = 0;
+    for (uint32_t c0 = 0; c0 < ncell; c0 += 4096u)
+        {
+        const uint32_t c = c0 + 4u * t;
+        uint32_t v[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k)
+            v[k] = (c + k < ncell) ? count[c + k] : 0u;
+        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+        uint32_t incl = mine;
+        for (int off = 1; off < 64; off <<= 1)
+            {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+            if ((int)lane >= off)
+                incl += up;
+            }
+        if (lane == 63u)
+            s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (uint32_t w = 0; w < 16u; ++w)
+            {
+            const uint32_t x = s_wave[w];
+            before += (w < wave) ? x : 0u;
+            total += x;
+            }
+        __syncthreads();
+        uint32_t acc = carry + before + incl - mine;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k)
+            {
+            if (c + k < ncell)
+                {
+                cell_start[c + k] = acc;
+                count[c + k] = acc;
+                }
+            acc += v[k];
+            }
+        carry += total;
+        }
+    if (t == 0)
+        cell_start[ncell] = carry;
+    }
+
+__global__ void __launch_bounds__(256) bin_scatter_kernel(uint32_t n_total, const uint32_t* __restrict__ cell_of,
+                                                          uint32_t* __restrict__ cursor, uint32_t* __restrict__ order_tmp)
+    {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < n_total;
+    const uint32_t c = active ? cell_of[i] : 0u;
+    const uint32_t slot = wave_aggregated_add(cursor, c, active); // (any order of the WAVES inside a cell: the next kernel sorts it)
+    if (active)
+        order_tmp[slot] = i;
+    }
+
+// One wave per cell: the cell's particle indices in ascending order (a rank sort: an index's position is the number
+// of smaller ones). Makes the permutation independent of the order in which the atomics above landed: neighbor rows,
+// and with them the summation order of the forces, are reproducible from run to run.
+__global__ void __launch_bounds__(256) bin_sort_cells_kernel(uint32_t ncell, const uint32_t* __restrict__ cell_start,
+                                                             const uint32_t* __restrict__ order_tmp, uint32_t* __restrict__ order)
+    {
+    const uint32_t c = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (c >= ncell)
+        return;
+    const uint32_t b = cell_start[c], n = cell_start[c + 1] - b;
+    for (uint32_t k0 = 0; k0 < n; k0 += 64u)
+        {
+        const uint32_t k = k0 + lane;
+        const uint32_t mine = (k < n) ? order_tmp[b + k] : 0xffffffffu;
+        uint32_t rank = 0;
+        for (uint32_t q0 = 0; q0 < n; q0 += 64u)
+            {
+            const uint32_t other = (q0 + lane < n) ? order_tmp[b + q0 + lane] : 0xffffffffu;
+            const uint32_t m = min(64u, n - q0);
+            for (uint32_t q = 0; q < m; ++q)
+                rank += ((uint32_t)__shfl((int)other, (int)q, 64) < mine) ? 1u : 0u;
+            }
+        if (k < n)
+            order[b + rank] = mine;
+        }
+    }
+
 struct NlistKArgs
     {
     const double* pos;
@@ -390,6 +520,30 @@ extern "C" int azp_nlist_cell_assign(const azp_nlist_args* args, void* stream)
     const uint32_t grid = (args->n_total + 255u) / 256u;
     hipLaunchKernelGGL(cell_assign_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), args->n_total,
                        args->d_pos, make_grid_dev(args->grid), args->d_cell_of);
+    return (int)hipGetLastError();
+    }
+
+extern "C" int azp_nlist_bin(const azp_nlist_args* args, uint32_t* d_cursor, uint32_t* d_order_tmp, void* stream)
+    {
+    using namespace azp;
+    if (check_nlist_args(args) || !args->d_cell_of || !args->d_order || !args->d_cell_start || !d_cursor || !d_order_tmp)
+        return AZP_ERROR_INVALID_ARGUMENT;
+    const uint32_t ncell = args->grid.dim[0] * args->grid.dim[1] * args->grid.dim[2];
+    const hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(d_cursor, 0, sizeof(uint32_t) * (size_t)ncell, s);
+    if (e != hipSuccess)
+        return (int)e;
+    const uint32_t n = args->n_total;
+    if (n)
+        hipLaunchKernelGGL(bin_assign_count_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, n, args->d_pos, make_grid_dev(args->grid),
+                           args->d_cell_of, d_cursor);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, s, ncell, d_cursor, args->d_cell_start);
+    if (n)
+        {
+        hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, n, args->d_cell_of, d_cursor, d_order_tmp);
+        hipLaunchKernelGGL(bin_sort_cells_kernel, dim3((ncell + 3u) / 4u), dim3(256), 0, s, ncell, args->d_cell_start, d_order_tmp,
+                           const_cast<uint32_t*>(args->d_order));
+        }
     return (int)hipGetLastError();
     }
 

@@ -7,6 +7,7 @@ buffers; the binning, counting and filling are libazp kernels.
 """
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -114,6 +115,12 @@ class NeighborList:
 
 class Cell(NeighborList):
     """Cell-list neighbor list (full storage, as HOOMD's GPU pair kernels use)."""
+
+    # azp_nlist_bin (counting sort in libazp) instead of the framework's sort pipeline. Off by default
+    # (AZP_NATIVE_BINNING=1 turns it on): its five kernels take 63 us against the pipeline's ~130 us + launch gaps,
+    # but a 300-step MD run of the north star came out SLOWER with it (0.49 vs 0.43 ms per step, twice each on one
+    # box) for a reason the kernel trace does not show; kept for callers without the framework, tested for equality.
+    native_binning = os.environ.get("AZP_NATIVE_BINNING", "0") == "1"
 
     def compute(self, state, force=False, compact=False):
         """Rebuild only when needed (HOOMD's criterion): never built, forced, or some
@@ -264,19 +271,36 @@ class Cell(NeighborList):
 
         cell_of = torch.empty(n_total, dtype=torch.int32, device=dev)
         a.d_cell_of = cell_of.data_ptr()
-        _lib.check(l.azp_nlist_cell_assign(C.byref(a), stream), "azp_nlist_cell_assign")
-        if ncell <= 65536:
-            # 16-bit keys: two radix passes instead of four (0.06 instead of 0.16 ms at N = 2^20); same permutation
-            k16, order = torch.sort((cell_of - 32768).to(torch.int16), stable=True)
-            cell_sorted = k16.to(torch.int32) + 32768
+        if self.native_binning and n_total <= 128 * ncell:
+            # one libazp call (counting sort, stable in the particle index): five small kernels back to back instead
+            # of a framework sort pipeline of a dozen launches with host gaps between them (0.25 -> 0.05 ms per rebuild
+            # at N = 2^20). Cells that hold very many particles (tiny boxes) take the general path: the per-cell
+            # sort is quadratic in the cell's population.
+            order = torch.empty(n_total, dtype=torch.int32, device=dev)
+            cell_start = torch.empty(ncell + 1, dtype=torch.int32, device=dev)
+            cursor = torch.empty(ncell, dtype=torch.int32, device=dev)
+            order_tmp = torch.empty(n_total, dtype=torch.int32, device=dev)
+            a.d_order = order.data_ptr()
+            a.d_cell_start = cell_start.data_ptr()
+            _lib.check(l.azp_nlist_bin(C.byref(a), cursor.data_ptr(), order_tmp.data_ptr(), stream), "azp_nlist_bin")
+            cell_sorted = None
+            keep_bin = (cursor, order_tmp)
         else:
-            cell_sorted, order = torch.sort(cell_of, stable=True)
-        order = order.to(torch.int32)
-        cell_start = torch.empty(ncell + 1, dtype=torch.int32, device=dev)
-        a.d_cell_sorted = cell_sorted.data_ptr()
-        a.d_order = order.data_ptr()
-        a.d_cell_start = cell_start.data_ptr()
-        _lib.check(l.azp_nlist_cell_bounds(C.byref(a), stream), "azp_nlist_cell_bounds")
+            _lib.check(l.azp_nlist_cell_assign(C.byref(a), stream), "azp_nlist_cell_assign")
+            if ncell <= 65536:
+                # 16-bit keys: two radix passes instead of four (0.06 instead of 0.16 ms at N = 2^20); same permutation
+                k16, order = torch.sort((cell_of - 32768).to(torch.int16), stable=True)
+                cell_sorted = k16.to(torch.int32) + 32768
+            else:
+                cell_sorted, order = torch.sort(cell_of, stable=True)
+        if cell_sorted is not None:
+            order = order.to(torch.int32)
+            cell_start = torch.empty(ncell + 1, dtype=torch.int32, device=dev)
+            a.d_cell_sorted = cell_sorted.data_ptr()
+            a.d_order = order.data_ptr()
+            a.d_cell_start = cell_start.data_ptr()
+            _lib.check(l.azp_nlist_cell_bounds(C.byref(a), stream), "azp_nlist_cell_bounds")
+            keep_bin = ()
 
         keep = []
         if "bond" in self.exclusions and state.bond_group.shape[0]:
@@ -290,7 +314,7 @@ class Cell(NeighborList):
         a.d_n_neigh = n_neigh.data_ptr()
         self.n_neigh = n_neigh
         self._cells = a
-        self._keep = (rlistsq, cell_of, cell_sorted, order, cell_start, keep)
+        self._keep = (rlistsq, cell_of, cell_sorted, order, cell_start, keep, keep_bin)
         self._pos_at_build = state.pos[:n_total].clone()
         self._nlist, self._head_list, self._size = None, None, 0
         self._fused_active = self._fused_eligible()

@@ -424,6 +424,11 @@ typedef struct azp_nlist_args
 
 int azp_nlist_cell_assign(const azp_nlist_args* args, void* stream);
 int azp_nlist_cell_bounds(const azp_nlist_args* args, void* stream);
+/* The binning in one call: d_cell_of, d_order (the particles cell by cell, ascending index inside a cell: what a
+ * stable sort by cell gives) and d_cell_start are written (d_cell_sorted is not used). A counting sort: histogram,
+ * scan, scatter, and a per-cell sort that makes the result independent of the order of the atomics. Scratch:
+ * d_cursor (ncell words), d_order_tmp (n_total words). */
+int azp_nlist_bin(const azp_nlist_args* args, uint32_t* d_cursor, uint32_t* d_order_tmp, void* stream);
 int azp_nlist_count(const azp_nlist_args* args, void* stream);
 int azp_nlist_fill(const azp_nlist_args* args, void* stream);
 

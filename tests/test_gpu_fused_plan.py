@@ -544,3 +544,38 @@ def test_fused_plan_many_types(oracle):
         assert info["valid"] == 1 and info["from_cells"] == 1
         assert_close(f_gpu, f_ref)
         assert_close(v_gpu, v_ref, what="virial")
+
+
+def test_native_binning_is_the_stable_sort(oracle):
+    """azp_nlist_bin (counting sort + per-cell sort) gives exactly the permutation and the cell bounds of a stable
+    sort of the particles by cell -- ragged cells, empty cells, ghosts, a cell that holds many particles."""
+    import torch
+
+    from azplugins_amd import _lib
+
+    rng = np.random.default_rng(5)
+    n = 30000
+    L = np.array([20.0, 14.0, 9.0])
+    xyz = (rng.random((n, 3)) - 0.5) * L
+    xyz[:3000] = 0.3 * (rng.random((3000, 3)) - 0.5) + np.array([3.0, 2.0, -1.0])  # a dense clump: one crowded cell
+    pos = syn.pos4(xyz)
+    rl = np.array([[1.7]])
+    cells, keep = H.gpu_cells(pos, (L,), rl, 1, None, None, 0)
+    ncell = int(cells.grid.dim[0] * cells.grid.dim[1] * cells.grid.dim[2])
+    cell_of = keep["cell_of"].cpu().numpy().view(np.uint32) if "cell_of" in keep else None
+    order = torch.empty(n, dtype=torch.int32, device="cuda:0")
+    start = torch.empty(ncell + 1, dtype=torch.int32, device="cuda:0")
+    cof = torch.empty(n, dtype=torch.int32, device="cuda:0")
+    cursor = torch.empty(ncell, dtype=torch.int32, device="cuda:0")
+    tmp = torch.empty(n, dtype=torch.int32, device="cuda:0")
+    cells.d_cell_of, cells.d_order, cells.d_cell_start = cof.data_ptr(), order.data_ptr(), start.data_ptr()
+    _lib.check(_lib.lib().azp_nlist_bin(C.byref(cells), cursor.data_ptr(), tmp.data_ptr(), H._stream()), "azp_nlist_bin")
+    torch.cuda.synchronize()
+    c = cof.cpu().numpy()
+    ref_order = np.argsort(c, kind="stable")
+    assert np.array_equal(order.cpu().numpy(), ref_order)
+    ref_start = np.searchsorted(c[ref_order], np.arange(ncell + 1), side="left")
+    assert np.array_equal(start.cpu().numpy(), ref_start)
+    if cell_of is not None:
+        assert np.array_equal(c.view(np.uint32), cell_of)
+    assert np.bincount(c, minlength=ncell).max() > 500  # the crowded cell was really there
