@@ -34,10 +34,10 @@ tail -4 $O/c3_md_noprof.log
 rocprofv3 --kernel-trace --stats -d $O/c4_stats --output-format csv -- python3 tools/xtiled_probe.py c4 > $O/c4.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/c5_stats --output-format csv -- python3 tools/xtiled_probe.py c5 > $O/c5.log 2>&1
 tail -1 $O/c4.log | cut -c1-300; tail -1 $O/c5.log | cut -c1-300
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d $O/c4_sq --output-format csv -- python3 tools/xtiled_probe.py c4 --reps 5 > $O/c4_sq.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/c4_fetch --output-format csv -- python3 tools/xtiled_probe.py c4 --reps 5 > $O/c4_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/c4_write --output-format csv -- python3 tools/xtiled_probe.py c4 --reps 5 > $O/c4_write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES -d $O/c5_sq --output-format csv -- python3 tools/xtiled_probe.py c5 --reps 5 > $O/c5_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d $O/c4_sq --output-format csv -- python3 tools/xtiled_probe.py c4 --reps 5 --settle-ms 0 > $O/c4_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/c4_fetch --output-format csv -- python3 tools/xtiled_probe.py c4 --reps 5 --settle-ms 0 > $O/c4_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/c4_write --output-format csv -- python3 tools/xtiled_probe.py c4 --reps 5 --settle-ms 0 > $O/c4_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES -d $O/c5_sq --output-format csv -- python3 tools/xtiled_probe.py c5 --reps 5 --settle-ms 0 > $O/c5_sq.log 2>&1
 python3 tools/plan_cells_probe.py 2>&1 | tail -1 | cut -c1-60 > $O/plan_cells.log
 python3 tools/plan_cells_probe.py --melt 100 2>&1 | tail -1 | cut -c1-60 >> $O/plan_cells.log
 cat $O/plan_cells.log
@@ -46,7 +46,7 @@ if [[ $PART == *c* ]]; then
 rocprofv3 --kernel-trace --stats -d $O/eval_stats --output-format csv -- python3 tools/evaluator_probe.py > $O/evaluators.log 2> $O/evaluators.err
 grep -v amdgpu $O/evaluators.log | grep "N="
 python3 tools/evaluator_probe.py 2>&1 | grep "N=" > $O/evaluators_noprof.log
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES -d $O/eval_sq --output-format csv -- python3 tools/evaluator_probe.py --reps 5 > $O/evaluators_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES -d $O/eval_sq --output-format csv -- python3 tools/evaluator_probe.py --reps 5 --settle-ms 0 > $O/evaluators_sq.log 2>&1
 python3 -m pytest tests/test_gpu_auto_plan.py -q -s -k plan_speed 2>&1 | grep "HOOMD-signature" > $O/entry.log
 cat $O/entry.log
 rocprofv3 --kernel-trace --stats -d $O/entry_stats --output-format csv -- python3 -m pytest tests/test_gpu_auto_plan.py -q -s -k plan_speed > $O/entry_prof.log 2>&1
