@@ -82,6 +82,10 @@ class NeighborList:
         pass
 
     def _stats(self):
+        """``n_pairs`` / ``max_neigh``. In fused mode (the plan compiled straight from the cells) the row lengths come
+        from the plan compiler, whose single-precision acceptance test keeps a superset of the exact list by a hair
+        (a few 1e-5 of the entries, all of them buffer entries the force kernel's exact cutoff test ignores): the
+        statistics are then UPPER BOUNDS of HOOMD's exact counts, and become exact once the list is materialized."""
         if not self._stats_known and self.n_neigh is not None:
             import torch
 
