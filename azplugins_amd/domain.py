@@ -269,10 +269,14 @@ class DeviceDomain:
         if n_send == 0:
             return names, buf
         if buf.is_cuda:
-            fields = (_lib.HaloField * len(names))()
-            for c, n in enumerate(names):
-                fields[c].d_data = self.arrays[n].data_ptr()
-                fields[c].row_bytes = self._row_bytes(n)
+            fkey = ("pack_fields", tuple(names))
+            if fkey not in self._bufs:  # (cleared at every rebuild, when the arrays are replaced)
+                fields = (_lib.HaloField * len(names))()
+                for c, n in enumerate(names):
+                    fields[c].d_data = self.arrays[n].data_ptr()
+                    fields[c].row_bytes = self._row_bytes(n)
+                self._bufs[fkey] = fields
+            fields = self._bufs[fkey]
             stream = torch.cuda.current_stream(self.device).cuda_stream
             _lib.check(_lib.lib().azp_halo_pack_fields(n_send, len(names), fields, self.send_idx.data_ptr(), buf.data_ptr(), wbytes, stream),
                        "azp_halo_pack_fields")
