@@ -296,3 +296,48 @@ def test_nve_step_two_one_is_step_two_then_step_one():
     for k in ("pos", "vel", "image"):
         assert np.array_equal(results[0][k], results[1][k]), k
     assert np.abs(results[0]["image"]).sum() > 0   # some particles did cross the boundary
+
+
+def test_sum_forces_and_displacements():
+    """azp_sum_forces (Integrator::computeNetForce in one pass) equals the element-wise sum; azp_nlist_displacements
+    writes every particle's displacement as a single-precision UPPER bound next to the maximum and the rebuild flag."""
+    import ctypes as C
+
+    import torch
+
+    from azplugins_amd import _lib
+
+    lib = _lib.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    n = 100_003
+    fs = [torch.randn((n, 4), dtype=torch.float64, device="cuda:0", generator=g) for _ in range(3)]
+    out = torch.full((n, 4), float("nan"), dtype=torch.float64, device="cuda:0")
+    ptrs = (C.c_void_p * 3)(*[f.data_ptr() for f in fs])
+    _lib.check(lib.azp_sum_forces(n, 3, ptrs, out.data_ptr(), stream), "azp_sum_forces")
+    assert torch.equal(out, (fs[0] + fs[1]) + fs[2])
+    # in place: the accumulator among the inputs
+    ptrs2 = (C.c_void_p * 2)(out.data_ptr(), fs[0].data_ptr())
+    ref = out + fs[0]
+    _lib.check(lib.azp_sum_forces(n, 2, ptrs2, out.data_ptr(), stream), "azp_sum_forces")
+    assert torch.equal(out, ref)
+
+    L = np.array([30.0, 20.0, 25.0])
+    rng = np.random.default_rng(9)
+    x0 = (rng.random((n, 3)) - 0.5) * L
+    d = rng.normal(size=(n, 3)) * 0.05
+    d[17] = [0.31, 0.0, 0.0]           # the one particle beyond the limit
+    x1 = syn.wrap(x0 + d, L)           # (some cross the periodic boundary: minimum image)
+    p0 = torch.from_numpy(syn.pos4(x0)).to("cuda:0")
+    p1 = torch.from_numpy(syn.pos4(x1)).to("cuda:0")
+    box = _lib.make_box(L)
+    row = torch.zeros(2, dtype=torch.int64, device="cuda:0")
+    disp = torch.full((n,), -1.0, dtype=torch.float32, device="cuda:0")
+    _lib.check(lib.azp_nlist_displacements(n, p1.data_ptr(), p0.data_ptr(), C.byref(box), 0.3 ** 2, row.data_ptr(), row.data_ptr() + 8,
+                                           disp.data_ptr(), stream), "azp_nlist_displacements")
+    flag, bits = row.tolist()
+    exact = np.linalg.norm(d, axis=1)
+    got = disp.cpu().numpy().astype(np.float64)
+    assert flag == 1
+    assert abs(np.sqrt(np.array([bits], dtype=np.int64).view(np.float64)[0]) - exact.max()) < 1e-12
+    assert np.all(got >= exact * (1 - 1e-15)) and np.all(got <= exact * (1 + 3e-7) + 1e-30)
