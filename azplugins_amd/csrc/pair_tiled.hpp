@@ -328,8 +328,17 @@ __device__ __forceinline__ void tiled_loop(const TiledKArgs& a, const char* bx, 
     {
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
     // chunk kk of this lane: uniform base + kk KiB (scalar) + 16 lane (one VGPR)
+#if defined(AZP_ABLATE) && (AZP_ABLATE == 4)
+    // ablation 4: HALF the index stream (8 bytes per lane and chunk, used twice): same LDS gathers, same arithmetic
+    auto chunk_at = [&](uint32_t kk) -> uint4
+        {
+        const uint2 h = *reinterpret_cast<const uint2*>(slice_base + (uint64_t)kk * 512u + (lane_off >> 1));
+        return make_uint4(h.x, h.y, h.x, h.y);
+        };
+#else
     auto chunk_at = [&](uint32_t kk) -> uint4
         { return *reinterpret_cast<const uint4*>(slice_base + (uint64_t)kk * 1024u + lane_off); };
+#endif
 #if AZP_TILE_BATCH == 4
     // (prefetching the chunk indices two iterations ahead instead of one costs 9 more
     // spilled registers and measures 3 % slower)
