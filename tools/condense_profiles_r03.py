@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense the output of tools/profile_passes_r03.sh (+ tools/r03_ag.sh) under gpurun_out/r03final into the files kept
+"""Condense the output of tools/profile_passes_r03.sh under gpurun_out/r03final into the files kept
 under profiles/ (r03_*).
 
     python tools/condense_profiles_r03.py gpurun_out/r03final

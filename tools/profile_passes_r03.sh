@@ -34,6 +34,10 @@ tail -4 $O/c3_md_noprof.log
 rocprofv3 --kernel-trace --stats -d $O/c4_stats --output-format csv -- python3 tools/xtiled_probe.py c4 > $O/c4.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/c5_stats --output-format csv -- python3 tools/xtiled_probe.py c5 > $O/c5.log 2>&1
 tail -1 $O/c4.log | cut -c1-300; tail -1 $O/c5.log | cut -c1-300
+python3 tools/xtiled_probe.py c4 2>&1 | tail -1 | cut -c1-200 > $O/c4_noprof.log; cat $O/c4_noprof.log
+python3 tools/xtiled_probe.py c5 2>&1 | tail -1 | cut -c1-200 > $O/c5_noprof.log; cat $O/c5_noprof.log
+rocprofv3 --kernel-trace --stats -d $O/bond_stats --output-format csv -- python3 tools/bond_probe.py > $O/bond.log 2>&1
+tail -1 $O/bond.log
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d $O/c4_sq --output-format csv -- python3 tools/xtiled_probe.py c4 --reps 5 --settle-ms 0 > $O/c4_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/c4_fetch --output-format csv -- python3 tools/xtiled_probe.py c4 --reps 5 --settle-ms 0 > $O/c4_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/c4_write --output-format csv -- python3 tools/xtiled_probe.py c4 --reps 5 --settle-ms 0 > $O/c4_write.log 2>&1
