@@ -457,6 +457,13 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
     uint16_t* raw_tile = a.raw + (uint64_t)tile * 256u * a.row_cap;
     const uint32_t trow = mytype * a.ntypes;
     const uint32_t nex = (a.n_excl && member) ? a.n_excl[i] : 0u;
+    // the member's first four exclusions (bonded partners: two for a bead inside a chain) in registers: the accept path
+    // compared every accepted candidate with the global table entry by entry (C3: 2.4 ms per build against 1.7 without bonds)
+    uint32_t ex4[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+#pragma unroll
+    for (uint32_t e = 0; e < 4u; ++e)
+        if (e < nex)
+            ex4[e] = a.excl[(uint64_t)e * a.excl_pitch + i];
 #ifdef AZP_PLAN_CELLS_PROFILE
     if ((a.stop_after & 255u) == 1u)
         return;
@@ -543,7 +550,12 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
                     const uint32_t ja = cj[c], jb = cj[c + 1u];
                     acca = acca && ja != i;
                     accb = accb && jb != i;
-                    for (uint32_t e = 0; e < nex; ++e)
+                    if (nex)
+                        {
+                        acca = acca && ja != ex4[0] && ja != ex4[1] && ja != ex4[2] && ja != ex4[3];
+                        accb = accb && jb != ex4[0] && jb != ex4[1] && jb != ex4[2] && jb != ex4[3];
+                        }
+                    for (uint32_t e = 4u; e < nex; ++e)
                         {
                         const uint32_t x = a.excl[(uint64_t)e * a.excl_pitch + i];
                         acca = acca && x != ja;
