@@ -135,7 +135,8 @@ void azp_last_launch(uint32_t* block_size, uint32_t* threads_per_particle, uint3
 
 int azp_tuning_set(int key, int value)
     {
-    int* slot = key == AZP_TUNE_ROW_PHASES ? &azp::tuning().row_phases : (key == AZP_TUNE_LOCAL_BOUND ? &azp::tuning().local_bound : nullptr);
+    int* slot = key == AZP_TUNE_ROW_PHASES ? &azp::tuning().row_phases
+                : (key == AZP_TUNE_LOCAL_BOUND ? &azp::tuning().local_bound : (key == AZP_TUNE_SPLIT_TILES ? &azp::tuning().split_tiles : nullptr));
     if (!slot)
         return -1;
     const int old = *slot;
@@ -158,6 +159,10 @@ Tuning& tuning()
         v.row_phases = (e && e[0] == '1');
         e = std::getenv("AZP_LOCAL_BOUND");
         v.local_bound = !(e && e[0] == '0');
+        // (off by default: two launches pay the ramp-down of a launch twice -- the liquid's force kernel measured
+        // 0.142-0.146 ms split against 0.135 ms in one launch of the 2,048-slot variant)
+        e = std::getenv("AZP_SPLIT_TILES");
+        v.split_tiles = (e && e[0] == '1');
         return v;
         }();
     return t;

@@ -579,6 +579,7 @@ void plan_free(PairPlan& p)
     if (p.d_slice_K) (void)hipFree(p.d_slice_K);
     if (p.d_slice_Kend) (void)hipFree(p.d_slice_Kend);
     if (p.d_slice_Kphase) (void)hipFree(p.d_slice_Kphase);
+    if (p.d_tile_ids) (void)hipFree(p.d_tile_ids);
     if (p.d_slice_head) (void)hipFree(p.d_slice_head);
     if (p.d_cnl) (void)hipFree(p.d_cnl);
     if (p.d_flags) (void)hipFree(p.d_flags);

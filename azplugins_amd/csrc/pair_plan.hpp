@@ -105,6 +105,15 @@ struct PairPlan
     // host copy of d_tile_nstage: a launch over a sub-range of tiles (domain-decomposed
     // runs: interior | boundary) picks the LDS variant from the tiles it covers
     std::vector<uint32_t> h_tile_nstage;
+    // Two launches by staged-set size (pair_tiled.hpp: launch_tiled_cap). In a liquid the staged sets spread (1,400 ..
+    // 1,850 at the north star's density): the largest one used to pick the LDS variant of the WHOLE launch (2,048 slots,
+    // three workgroups per CU) although four tiles in five fit the 1,664-slot variant (four per CU). Tile numbers of the
+    // two groups, small first; made on the first launch after a build from h_tile_nstage.
+    mutable std::vector<uint32_t> h_tile_ids;
+    mutable uint32_t* d_tile_ids = nullptr;
+    mutable size_t cap_tile_ids = 0;
+    mutable uint64_t tile_ids_build = 0;
+    mutable uint32_t n_small_tiles = 0;
     };
 
 // Buffer shells a launch has to walk, from the caller's displacement bound: an entry of

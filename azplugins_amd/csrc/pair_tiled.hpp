@@ -75,6 +75,8 @@ struct TiledKArgs
     // was at least r_cut + s w away, and the two particles of a pair have closed in by at most the sum of their own
     // displacements <= 2 x the largest one in the tile -- instead of the shells the fastest particle of the whole system
     // dictates. bound_extra is added to every entry (a plan compiled later than the positions the displacements refer to).
+    const uint32_t* tile_ids;     // NULL: workgroup b computes tile first / TB + b; else tile_ids[b], b < n_tile_ids
+    uint32_t n_tile_ids;
     const TileDyn* dyn;           // NULL: n_shells / bound above are final
     // the same idea with the raw words of the neighbor list's distance check (azp_pair_args.d_stale_flag,
     // d_displacement_sq_bits): leave when *dflag != 0, bound = sqrt(double(*dbits)) + bound_extra
@@ -427,7 +429,14 @@ __global__ void __launch_bounds__(256, E::kTileWaves) pair_forces_tiled_kernel(c
     unsigned long long tl_tb = 0, tl_tc = 0, tl_td = 0, tl_ta = 0;
 #endif
     // a.p.first / a.p.end are tile-aligned outwards by the launcher
-    const uint32_t tile = a.p.first / TB + xcd_remap(blockIdx.x, a.p.nblocks_padded);
+    uint32_t tile = a.p.first / TB + xcd_remap(blockIdx.x, a.p.nblocks_padded);
+    if (a.tile_ids)
+        {
+        const uint32_t b = xcd_remap(blockIdx.x, a.p.nblocks_padded);
+        if (b >= a.n_tile_ids)
+            return;
+        tile = a.tile_ids[b];
+        }
     const uint32_t first = tile * TB;
     if (first >= a.p.end)
         return;
@@ -697,7 +706,7 @@ __global__ void __launch_bounds__(256, E::kTileWaves) pair_forces_tiled_kernel(c
 
 template<class E, int TPP, int CAP, bool VIRIAL, bool SINGLE, bool XPLOR>
 int launch_tiled_instance2(const PairPlan& plan, const azp_pair_args& args, const typename E::Params* d_params,
-                          hipStream_t stream, const TileDyn* dyn)
+                          hipStream_t stream, const TileDyn* dyn, const uint32_t* tile_ids = nullptr, uint32_t n_tile_ids = 0)
     {
     TiledKArgs k = {};
     k.p = make_pair_kargs(args);
@@ -724,7 +733,9 @@ int launch_tiled_instance2(const PairPlan& plan, const azp_pair_args& args, cons
     const uint32_t t0 = k.p.first / tb, t1 = (k.p.end + tb - 1) / tb;
     k.p.first = t0 * tb;
     k.p.end = (t1 * tb < args.N) ? t1 * tb : args.N;
-    const uint32_t nblocks = (t1 - t0 + 7u) & ~7u;
+    k.tile_ids = tile_ids;
+    k.n_tile_ids = n_tile_ids;
+    const uint32_t nblocks = ((tile_ids ? n_tile_ids : t1 - t0) + 7u) & ~7u;
     k.p.nblocks_padded = nblocks;
     size_t lds = (size_t)AZP_TILE_STRIDE(CAP) * 24 + (SINGLE ? 0 : (size_t)CAP * 4 + 8);
     if (!SINGLE)
@@ -747,11 +758,44 @@ int launch_tiled_instance2(const PairPlan& plan, const azp_pair_args& args, cons
 
 template<class E, int TPP, int CAP, bool VIRIAL, bool SINGLE>
 int launch_tiled_instance(const PairPlan& plan, const azp_pair_args& args, const typename E::Params* d_params,
-                          hipStream_t stream, const TileDyn* dyn)
+                          hipStream_t stream, const TileDyn* dyn, const uint32_t* tile_ids = nullptr, uint32_t n_tile_ids = 0)
     {
     if (args.shift_mode == AZP_SHIFT_XPLOR)
-        return launch_tiled_instance2<E, TPP, CAP, VIRIAL, SINGLE, true>(plan, args, d_params, stream, dyn);
-    return launch_tiled_instance2<E, TPP, CAP, VIRIAL, SINGLE, false>(plan, args, d_params, stream, dyn);
+        return launch_tiled_instance2<E, TPP, CAP, VIRIAL, SINGLE, true>(plan, args, d_params, stream, dyn, tile_ids, n_tile_ids);
+    return launch_tiled_instance2<E, TPP, CAP, VIRIAL, SINGLE, false>(plan, args, d_params, stream, dyn, tile_ids, n_tile_ids);
+    }
+
+// tile numbers of the two groups of a split launch (see PairPlan::h_tile_ids), uploaded once per build
+inline int plan_split_tiles(const PairPlan& plan, hipStream_t s)
+    {
+    if (plan.tile_ids_build == plan.builds && plan.d_tile_ids)
+        return AZP_SUCCESS;
+    const uint32_t n = plan.n_tiles;
+    plan.h_tile_ids.resize(n);
+    uint32_t small = 0;
+    for (uint32_t t = 0; t < n; ++t)
+        if (plan.h_tile_nstage[t] + 1u <= 1664u)
+            plan.h_tile_ids[small++] = t;
+    uint32_t large = small;
+    for (uint32_t t = 0; t < n; ++t)
+        if (plan.h_tile_nstage[t] + 1u > 1664u)
+            plan.h_tile_ids[large++] = t;
+    if (plan.cap_tile_ids < n)
+        {
+        if (plan.d_tile_ids) (void)hipFree(plan.d_tile_ids);
+        plan.d_tile_ids = nullptr;
+        plan.cap_tile_ids = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&plan.d_tile_ids), sizeof(uint32_t) * (size_t)(n + 64));
+        if (e != hipSuccess)
+            return (int)e;
+        plan.cap_tile_ids = n + 64;
+        }
+    hipError_t e = hipMemcpyAsync(plan.d_tile_ids, plan.h_tile_ids.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess)
+        return (int)e;
+    plan.n_small_tiles = small;
+    plan.tile_ids_build = plan.builds;
+    return AZP_SUCCESS;
     }
 
 template<class E, int TPP, bool VIRIAL, bool SINGLE>
@@ -768,6 +812,23 @@ int launch_tiled_cap(const PairPlan& plan, const azp_pair_args& args, const type
         for (uint32_t t = t0; t < t1 && t < plan.n_tiles; ++t)
             most = plan.h_tile_nstage[t] > most ? plan.h_tile_nstage[t] : most;
         cap = plan_cap_for(most);
+        }
+    if (TPP == 1 && args.range_count == 0 && cap > 1664u && tuning().split_tiles && plan.h_tile_nstage.size() == plan.n_tiles)
+        {
+        // a liquid: the tiles that fit the 1,664-slot variant (four workgroups per CU) first, then the rest
+        const int rc = plan_split_tiles(plan, s);
+        if (rc != AZP_SUCCESS)
+            return rc;
+        const uint32_t n_small = plan.n_small_tiles, n_large = plan.n_tiles - n_small;
+        if (n_small * 2u >= plan.n_tiles && n_large > 0)
+            {
+            const int r1 = launch_tiled_instance<E, TPP, 1664, VIRIAL, SINGLE>(plan, args, d_params, s, dyn, plan.d_tile_ids, n_small);
+            if (r1 != AZP_SUCCESS)
+                return r1;
+            if (cap == 2048u)
+                return launch_tiled_instance<E, TPP, 2048, VIRIAL, SINGLE>(plan, args, d_params, s, dyn, plan.d_tile_ids + n_small, n_large);
+            return launch_tiled_instance<E, TPP, 2560, VIRIAL, SINGLE>(plan, args, d_params, s, dyn, plan.d_tile_ids + n_small, n_large);
+            }
         }
     switch (cap)
         {

@@ -585,10 +585,12 @@ void azp_last_launch(uint32_t* block_size, uint32_t* threads_per_particle, uint3
 /* Process-wide switches of the tile kernels, for A/B measurements (results are identical either way):
  * AZP_TUNE_ROW_PHASES (default 0: it measures 1.5 % slower on the north star although it issues fewer
  * instructions): the test-free / core-test-free parts of a row (csrc/pair_tiled.hpp);
- * AZP_TUNE_LOCAL_BOUND (default 1): azp_pair_args.d_displacement is used when given.
+ * AZP_TUNE_LOCAL_BOUND (default 1): azp_pair_args.d_displacement is used when given;
+ * AZP_TUNE_SPLIT_TILES (default 0: measured 5 % slower; AZP_SPLIT_TILES=1): plans whose largest staged set needs more than
+ * 1,664 LDS slots are launched in two parts, the tiles that fit the 1,664-slot variant (four workgroups per CU) and the rest.
  * Returns the previous value, or -1 for an unknown key. The environment variables AZP_ROW_PHASES=1 /
  * AZP_LOCAL_BOUND=0 set the initial values. */
-enum { AZP_TUNE_ROW_PHASES = 1, AZP_TUNE_LOCAL_BOUND = 2 };
+enum { AZP_TUNE_ROW_PHASES = 1, AZP_TUNE_LOCAL_BOUND = 2, AZP_TUNE_SPLIT_TILES = 3 };
 int azp_tuning_set(int key, int value);
 
 #ifdef __cplusplus
