@@ -395,7 +395,6 @@ int auto_plan_run(const azp_pair_args& args, bool lanes_one, hipStream_t stream,
     const uint64_t call = e->calls++;
 
     bool stale = true;
-    double bound = 0.0;
     // (a caller that passes list generations: a changed generation needs no check to be known stale; one that
     // stops passing them, or starts to, gets a fresh compile)
     const bool comparable = e->have_plan && e->n_max == args.n_max && e->d_pos0 && args.list_generation == e->generation;
@@ -413,6 +412,8 @@ int auto_plan_run(const azp_pair_args& args, bool lanes_one, hipStream_t stream,
             a.has_displacement_bound = 1;
             a.displacement_bound = 0.0; // (the kernel takes shell count and bound from the device words)
             a.d_displacement = nullptr;
+            a.d_stale_flag = nullptr;   // (those belong to callers that run their own distance check)
+            a.d_displacement_sq_bits = nullptr;
             const AutoLaunch l = {&e->plan, &a, &e->d_state->dyn};
             const int status = launch_tiled(l);
             if (status != AZP_SUCCESS)
@@ -420,7 +421,6 @@ int auto_plan_run(const azp_pair_args& args, bool lanes_one, hipStream_t stream,
             }
         AZP_AUTO_TRY(hipStreamSynchronize(e->side));
         stale = e->h_state->dyn.stale != 0;
-        bound = e->h_state->dyn.bound;
         if (!stale)
             {
             ++g_stats.reuses;
@@ -434,7 +434,6 @@ int auto_plan_run(const azp_pair_args& args, bool lanes_one, hipStream_t stream,
     const int status = compile_plan(*e, args, stream);
     if (status != AZP_SUCCESS)
         return status;
-    (void)bound;
     if (!e->plan.valid)
         {
         ++g_stats.generic_fallbacks;
@@ -444,6 +443,8 @@ int auto_plan_run(const azp_pair_args& args, bool lanes_one, hipStream_t stream,
     a.has_displacement_bound = 1;
     a.displacement_bound = 0.0; // compiled from these very positions
     a.d_displacement = nullptr;
+    a.d_stale_flag = nullptr;
+    a.d_displacement_sq_bits = nullptr;
     const AutoLaunch l = {&e->plan, &a, nullptr};
     return launch_tiled(l);
     }
