@@ -28,12 +28,21 @@ ap.add_argument("--workload", default="ns", help="ns: the north-star liquid (Per
 ap.add_argument("--buffer", type=float, default=None, help="neighbor-list buffer r_buff (default: the workload's 0.4; HOOMD users tune it)")
 args = ap.parse_args()
 
-cfg = syn.config_north_star(args.ncell) if args.workload == "ns" else syn.config_chains()
+cfg = {"ns": lambda: syn.config_north_star(args.ncell), "c3": syn.config_chains, "c5": syn.config_tpm, "c4": syn.config_dpd}[args.workload]()
 N = cfg["xyz"].shape[0]
 sim = azp.Simulation(device="cuda:0", seed=1)
-sim.create_state_from_snapshot(azp.Snapshot.from_arrays(cfg["xyz"], cfg["L"], bonds=cfg.get("bonds") if args.workload == "c3" else None))
+snap = azp.Snapshot.from_arrays(cfg["xyz"], cfg["L"], bonds=cfg.get("bonds") if args.workload == "c3" else None, orientation=cfg.get("orientation"),
+                                velocity=cfg.get("vel"), tag=cfg.get("tag"))
+if args.workload == "c5":
+    snap.particles.moment_inertia[:] = [0.1, 0.12, 0.14]
+sim.create_state_from_snapshot(snap)
 nl = azp.nlist.Cell(buffer=args.buffer if args.buffer is not None else cfg["r_buff"])
-pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=cfg["r_cut"])
+if args.workload == "c5":
+    pot = azp.pair.TwoPatchMorse(nlist=nl, default_r_cut=cfg["r_cut"], mode="shift")
+elif args.workload == "c4":
+    pot = azp.pair.DPDGeneralWeight(nlist=nl, kT=cfg["kT"], default_r_cut=cfg["r_cut"])
+else:
+    pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=cfg["r_cut"])
 pot.params[("A", "A")] = cfg["params"]
 pot.use_plan = not args.no_plan
 forces = [pot]
@@ -41,12 +50,13 @@ if args.workload == "c3":
     dw = azp.bond.DoubleWell()
     dw.params["A-A"] = cfg["bond_params"]
     forces.append(dw)
-sim.operations.integrator = azp.Integrator(dt=args.dt, forces=forces, methods=[azp.ConstantVolume()])
+sim.operations.integrator = azp.Integrator(dt=args.dt, forces=forces, methods=[azp.ConstantVolume()], integrate_rotational_dof=(args.workload == "c5"))
 sim.operations.tuners.clear()
 if args.sort_period:
     sim.operations.tuners.append(azp.ParticleSorter(trigger_period=args.sort_period, curve=args.curve))
 sim.run(0)
-sim.thermalize_particle_momenta(args.kT, seed=7)
+if args.workload != "c4":
+    sim.thermalize_particle_momenta(args.kT, seed=7)
 sim.run(50)  # melt the lattice a little, warm the allocator
 torch.cuda.synchronize()
 b0 = nl.num_builds
