@@ -73,7 +73,11 @@ class Bond(Force):
         self._ensure_buffers()
         if self._tables is None:
             self._build_tables()
-            self._flags.zero_()  # (new parameters: the sticky "rejected" flag starts over)
+            self._flags.zero_()  # (new parameters: the sticky "rejected" flag starts over, on the device and on the host)
+            self._flag_pending = None
+            if getattr(self, "_flag_host", None) is not None:
+                getattr(self, "_flag_side").synchronize()
+                self._flag_host.zero_()
         tab = st.bond_table()
         a = _lib.BondArgs()
         a.d_force = self._force.data_ptr()

@@ -121,6 +121,26 @@ def test_bond_invalid_parameters_raise():
         sim.run(0)
 
 
+def test_bond_invalid_parameters_raise_inside_a_run():
+    """The same error when the parameters go bad in the middle of a run: inside Simulation.run the bond evaluators' flag is
+    examined when the NEXT step is queued and once more after the loop (no host round trip behind every launch), so the
+    run still ends in the error; and a force with sane parameters again works afterwards."""
+    sim = azp.Simulation(device="cuda:0", seed=1)
+    sim.create_state_from_snapshot(azp.bonded_two_particle_snapshot(d=1.0))
+    integrator = azp.Integrator(dt=0.001, methods=[azp.ConstantVolume()])
+    potential = azp.bond.DoubleWell()
+    potential.params["A-A"] = dict(r_0=1.0, r_1=1.5, U_1=1.0, U_tilt=0.5)
+    integrator.forces = [potential]
+    sim.operations.integrator = integrator
+    sim.run(3)
+    potential.params["A-A"] = dict(r_0=1.0, r_1=1.0, U_1=1.0, U_tilt=0.0)
+    with pytest.raises(azp.AzpError):
+        sim.run(5)
+    potential.params["A-A"] = dict(r_0=1.0, r_1=1.5, U_1=1.0, U_tilt=0.5)
+    sim.run(2)
+    assert np.all(np.isfinite(potential.forces))
+
+
 def test_dpd_temperature():
     """src/pytest/test_pair_dpd.py:13-46 restated: N=1000 on a 10^3 lattice
     (a=0.6), thermalised at kT=1.5, DPD with A=0 (drag + random only), NVE,
