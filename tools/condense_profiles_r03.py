@@ -143,5 +143,9 @@ ab += ["```", "", "phases = the test-free / core-test-free row phases (azp_tunin
        "(azp_pair_args.d_displacement). Both are exact; both issue fewer LDS gathers or VALU instructions and both run SLOWER: off by default."]
 if os.path.exists(os.path.join(O, "entry.log")):
     ab += ["", "# The HOOMD-signature entry (tests/test_gpu_auto_plan.py::test_hoomd_signature_entry_runs_at_plan_speed, N = 2^20)", "", "```", open(os.path.join(O, "entry.log")).read().strip(), "```"]
+for f in ("c4_noprof.log", "c5_noprof.log"):
+    fn = os.path.join(O, f.replace("_noprof", "_entry"))
+    if os.path.exists(fn):
+        ab += ["", "```", open(fn).read().strip(), "```"]
 open(os.path.join(P, "r03_ab_and_entry.md"), "w").write("\n".join(ab) + "\n")
 print("\n".join(md[:40]))

@@ -61,5 +61,43 @@ pot.use_displacement_bound = False
 t_whole = timed()
 pot.use_plan = False
 t_gen = timed()
+# the entry the reference's kernel driver forwards to (gpu_compute_dpd_forces / gpu_compute_pair_aniso_forces ->
+# azp_dpd_forces_general_weight / azp_aniso_forces_two_patch_morse) with libazp's own plan cache: list check + tile kernel
+import ctypes as C
+import time
+
+nl.fused = False          # HOOMD hands its own u32 list to the entry point: build one
+pot.use_plan = True
+pot._plan_builds = None
+nl.compute(sim.state, force=True)
+pot.compute(0)
+a = pot._pair_args()
+a.r_list_max = 0.0        # pair_args_t has no such field
+a.has_displacement_bound = 0
+a.flags = 0
+a.threads_per_particle = 0
+cargs = pot._wrap_args(a, 0)
+lib = azp._lib.lib()
+lib.azp_pair_auto_plan_clear()
+fn = getattr(lib, pot._entry)
+params = pot._tables["params"].data_ptr()
+stream = torch.cuda.current_stream().cuda_stream
+for _ in range(3):
+    azp._lib.check(fn(C.byref(cargs), params, stream), pot._entry)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+while (time.perf_counter() - t0) * 1e3 < args.settle_ms:
+    for _ in range(20):
+        azp._lib.check(fn(C.byref(cargs), params, stream), pot._entry)
+    torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(args.reps):
+    azp._lib.check(fn(C.byref(cargs), params, stream), pot._entry)
+torch.cuda.synchronize()
+t_entry = (time.perf_counter() - t0) / args.reps * 1e3
+st = azp._lib.auto_plan_stats()
+lib.azp_pair_auto_plan_clear()
+print("%s: HOOMD-signature entry with the plan cache %.4f ms per call on the host (reuses %d, generic fallbacks %d)" % (
+    args.which, t_entry, st["reuses"], st["generic_fallbacks"]))
 print("%s: tile-staged %.4f ms (bound 0) / %.4f ms (whole rows), generic %.4f ms; plan %s; launch %s" % (
     args.which, t_plan, t_whole, t_gen, {k: info[k] for k in ("valid", "lds_slots", "max_stage", "tile_size")}, azp._lib.last_launch()))
