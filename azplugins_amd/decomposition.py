@@ -458,15 +458,18 @@ def bench_main(args, rank, world, local_rank):
     # run-in to the sustained clock before the warmup, as bench.py does at N = 1 (profiles/r03_clock_transient.md)
     settle_ms = getattr(args, "settle_ms", 80.0)
     t_settle = time.perf_counter()
-    while (time.perf_counter() - t_settle) * 1e3 < settle_ms:
+    while settle_ms > 0.0:
         for _ in range(20):
             step()
         torch.cuda.synchronize()
-        if world > 1:  # every rank leaves the loop in the same pass (the step holds a collective)
-            flag = torch.tensor([1.0 if (time.perf_counter() - t_settle) * 1e3 < settle_ms else 0.0], device=dev if backend == "nccl" else "cpu")
+        # every rank leaves the loop in the same pass (the step holds a collective): the decision is collective too
+        more = 1.0 if (time.perf_counter() - t_settle) * 1e3 < settle_ms else 0.0
+        if world > 1:
+            flag = torch.tensor([more], device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if float(flag.item()) == 0.0:
-                break
+            more = float(flag.item())
+        if more == 0.0:
+            break
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
