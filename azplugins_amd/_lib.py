@@ -122,11 +122,6 @@ class NVEArgs(C.Structure):
         ("dt", C.c_double),
         ("N", C.c_uint32),
         ("block_size", C.c_uint32),
-        ("d_pos_at_build", C.c_void_p),
-        ("max_dist_sq", C.c_double),
-        ("d_check_flag", C.c_void_p),
-        ("d_check_max_bits", C.c_void_p),
-        ("d_check_disp", C.c_void_p),
     ]
 
 

@@ -134,12 +134,6 @@ struct NVEKArgs
     BoxDev box;
     double dt;
     uint32_t N;
-    // the neighbor list's distance check fused into step one (azp_nve_args.d_pos_at_build ...)
-    const double* pos0;
-    double max_dist_sq;
-    uint32_t* check_flag;
-    unsigned long long* check_max_bits;
-    float* check_disp;
     };
 
 // MODE 0: step two (v += a dt/2). 1: step one (v += a dt/2, x += v dt, wrap). 2: step two of one step and step
@@ -150,77 +144,35 @@ template<int MODE> __global__ void __launch_bounds__(256) nve_kernel(const NVEKA
     {
     constexpr bool STEP_ONE = MODE != 0;
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = idx < a.N;
-    if (!active && !(STEP_ONE && a.pos0))
-        return; // (with the fused distance check every lane stays for the workgroup's reduction)
-    double dsq = 0.0;
-    if (active)
+    if (idx >= a.N)
+        return;
+    double4 v = load_scalar4(a.vel, idx);
+    const double4 f = load_scalar4(a.net_force, idx);
+    const double minv = 1.0 / v.w;
+    const double hdt = 0.5 * a.dt;
+    if (MODE == 2)
         {
-        double4 v = load_scalar4(a.vel, idx);
-        const double4 f = load_scalar4(a.net_force, idx);
-        const double minv = 1.0 / v.w;
-        const double hdt = 0.5 * a.dt;
-        if (MODE == 2)
-            {
-            v.x += hdt * f.x * minv; v.y += hdt * f.y * minv; v.z += hdt * f.z * minv;
-            }
         v.x += hdt * f.x * minv; v.y += hdt * f.y * minv; v.z += hdt * f.z * minv;
-        store_scalar4(a.vel, idx, v.x, v.y, v.z, v.w);
-        if (STEP_ONE)
-            {
-            const double4 p = load_scalar4(a.pos, idx);
-            double x = p.x + a.dt * v.x, y = p.y + a.dt * v.y, z = p.z + a.dt * v.z;
-            const double x0 = x, y0 = y, z0 = z;
-            wrap_into_box(a.box, x, y, z);
-            store_scalar4(a.pos, idx, x, y, z, p.w);
-            if (a.image)
-                {
-                // which way was it wrapped (orthorhombic shortcut is exact; for triclinic
-                // boxes the z shift is read off z, the y shift off y after removing z's tilt)
-                const int iz = (z < z0) - (z > z0);
-                const double y1 = y0 - iz * a.box.Lz * a.box.yz;
-                const int iy = (y < y1) - (y > y1);
-                const double x1 = x0 - iz * a.box.Lz * a.box.xz - iy * a.box.Ly * a.box.xy;
-                const int ix = (x < x1) - (x > x1);
-                a.image[3 * idx + 0] += ix; a.image[3 * idx + 1] += iy; a.image[3 * idx + 2] += iz;
-                }
-            if (a.pos0)
-                {
-                // the neighbor list's distance check on the position just written (nlist.hip: distance_check_kernel)
-                const double3 q = load_scalar3_of4(a.pos0, idx);
-                double dx = x - q.x, dy = y - q.y, dz = z - q.z;
-                min_image(a.box, dx, dy, dz);
-                dsq = dx * dx + dy * dy + dz * dz;
-                if (a.check_disp)
-                    {
-                    const double d = sqrt(dsq) * (1.0 + 1e-15);
-                    a.check_disp[idx] = (d == d) ? __double2float_ru(d) : __int_as_float(0x7f800000);
-                    }
-                }
-            }
         }
-    if (STEP_ONE && a.pos0)
+    v.x += hdt * f.x * minv; v.y += hdt * f.y * minv; v.z += hdt * f.z * minv;
+    store_scalar4(a.vel, idx, v.x, v.y, v.z, v.w);
+    if (STEP_ONE)
         {
-        for (int off = 32; off > 0; off >>= 1)
-            dsq = fmax(dsq, __shfl_xor(dsq, off, 64));
-        __shared__ double s_wave_max[4];
-        if ((threadIdx.x & 63) == 0)
-            s_wave_max[threadIdx.x >> 6] = dsq;
-        __syncthreads();
-        if (threadIdx.x == 0)
+        const double4 p = load_scalar4(a.pos, idx);
+        double x = p.x + a.dt * v.x, y = p.y + a.dt * v.y, z = p.z + a.dt * v.z;
+        const double x0 = x, y0 = y, z0 = z;
+        wrap_into_box(a.box, x, y, z);
+        store_scalar4(a.pos, idx, x, y, z, p.w);
+        if (a.image)
             {
-            const uint32_t nw = (blockDim.x + 63u) >> 6;
-            double m = s_wave_max[0];
-            for (uint32_t w = 1; w < nw; ++w)
-                m = fmax(m, s_wave_max[w]);
-            if (m > a.max_dist_sq)
-                atomicOr(a.check_flag, 1u);
-            if (a.check_max_bits && m > 0.0)
-                {
-                const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
-                if (bits > *reinterpret_cast<volatile unsigned long long*>(a.check_max_bits))
-                    atomicMax(a.check_max_bits, bits);
-                }
+            // which way was it wrapped (orthorhombic shortcut is exact; for triclinic
+            // boxes the z shift is read off z, the y shift off y after removing z's tilt)
+            const int iz = (z < z0) - (z > z0);
+            const double y1 = y0 - iz * a.box.Lz * a.box.yz;
+            const int iy = (y < y1) - (y > y1);
+            const double x1 = x0 - iz * a.box.Lz * a.box.xz - iy * a.box.Ly * a.box.xy;
+            const int ix = (x < x1) - (x > x1);
+            a.image[3 * idx + 0] += ix; a.image[3 * idx + 1] += iy; a.image[3 * idx + 2] += iz;
             }
         }
     }
@@ -244,12 +196,6 @@ template<int MODE> static int launch_nve(const azp_nve_args* args, void* stream)
     k.box = make_box_dev(args->box);
     k.dt = args->dt;
     k.N = args->N;
-    const bool check = MODE != 0 && args->d_pos_at_build && args->d_check_flag;
-    k.pos0 = check ? args->d_pos_at_build : nullptr;
-    k.max_dist_sq = args->max_dist_sq;
-    k.check_flag = args->d_check_flag;
-    k.check_max_bits = args->d_check_max_bits;
-    k.check_disp = args->d_check_disp;
     const uint32_t grid = (args->N + bs - 1) / bs;
     hipLaunchKernelGGL(nve_kernel<MODE>, dim3(grid), dim3(bs), 0, static_cast<hipStream_t>(stream), k);
     return (int)hipGetLastError();

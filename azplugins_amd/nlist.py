@@ -160,10 +160,11 @@ class Cell(NeighborList):
         largest displacement since the build (``displacement_bound``)."""
         return self.end_check(self.begin_check(state))
 
-    def reserve_check(self, state):
-        """The device words and arrays one distance check writes (a fresh [flag, max |dx|^2 bits] row of the ring, the
-        per-particle displacement array), for a caller that runs the check inside a kernel of its own
-        (Simulation.run: step one of the integrator, azp_nve_args.d_pos_at_build ...)."""
+    def begin_check(self, state):
+        """Queue the distance check on the current stream and its 16-byte readback on a side stream (ordered after
+        the check alone). Returns a token for ``end_check``; ``token["flag_ptr"]`` / ``token["bits_ptr"]`` are the
+        device words a force kernel queued right behind the check can read (azp_pair_args.d_stale_flag,
+        d_displacement_sq_bits), so that the host's wait for the result does not idle the GPU."""
         import torch
 
         # [flag, max |dx|^2 bits] per check, a ring of 64 rows zeroed once per 64 checks (not a fill kernel per step)
@@ -177,43 +178,22 @@ class Cell(NeighborList):
             self._flag_i = 0
         row = self._flag[self._flag_i]
         self._flag_i += 1
+        box = state.box.to_c()
+        stream = _lib.raw_stream(state.device)
         # every particle's own displacement next to the maximum: the tile kernels can take the maximum over what a
         # tile stages (azp_pair_args.d_displacement) instead of the global one
         if getattr(self, "_disp_arr", None) is None or self._disp_arr.shape[0] != state.n_max or self._disp_arr.device != state.pos.device:
             self._disp_arr = torch.zeros(state.n_max, dtype=torch.float32, device=state.pos.device)
-        return dict(row=row, flag_ptr=row.data_ptr(), bits_ptr=row.data_ptr() + 8, disp_ptr=self._disp_arr.data_ptr(),
-                    pos0_ptr=self._pos_at_build.data_ptr(), max_dist_sq=(0.5 * self.buffer) ** 2)
-
-    def check_was_queued(self, state, reserved):
-        """The caller's kernel has run the check ``reserved`` describes on the positions of the state's CURRENT generation."""
-        self._prelaunched = (state.position_generation, reserved)
-
-    def begin_check(self, state):
-        """Queue the distance check on the current stream (unless the integrator's step one ran it already:
-        ``check_was_queued``) and its 16-byte readback on a side stream (ordered after the check alone). Returns a
-        token for ``end_check``; ``token["flag_ptr"]`` / ``token["bits_ptr"]`` are the device words a force kernel
-        queued right behind the check can read (azp_pair_args.d_stale_flag, d_displacement_sq_bits), so that the
-        host's wait for the result does not idle the GPU."""
-        import torch
-
-        pre = getattr(self, "_prelaunched", None)
-        self._prelaunched = None
-        if pre is not None and pre[0] == state.position_generation:
-            r = pre[1]
-        else:
-            r = self.reserve_check(state)
-            box = state.box.to_c()
-            stream = _lib.raw_stream(state.device)
-            _lib.check(_lib.lib().azp_nlist_displacements(state.n_max, state.pos.data_ptr(), r["pos0_ptr"], C.byref(box), r["max_dist_sq"],
-                                                          r["flag_ptr"], r["bits_ptr"], r["disp_ptr"], stream),
-                       "azp_nlist_displacements")
-        row = r["row"]
+        _lib.check(_lib.lib().azp_nlist_displacements(state.n_max, state.pos.data_ptr(), self._pos_at_build.data_ptr(),
+                                                      C.byref(box), (0.5 * self.buffer) ** 2, row.data_ptr(),
+                                                      row.data_ptr() + 8, self._disp_arr.data_ptr(), stream),
+                   "azp_nlist_displacements")
         done = torch.cuda.Event()
         done.record()
         with torch.cuda.stream(self._side):
             self._side.wait_event(done)
             self._host_row.copy_(row, non_blocking=True)
-        return dict(flag_ptr=r["flag_ptr"], bits_ptr=r["bits_ptr"], generation=state.position_generation, row=row)
+        return dict(flag_ptr=row.data_ptr(), bits_ptr=row.data_ptr() + 8, generation=state.position_generation, row=row)
 
     def end_check(self, token):
         """Wait for the check of ``begin_check`` (not for anything queued after it); True: rebuild."""

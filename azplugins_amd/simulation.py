@@ -215,15 +215,6 @@ class Simulation:
                 t += f.torque_tensor
             return t
 
-        # The neighbor list's distance check rides in step one of the integrator (one pass fewer over the positions,
-        # one kernel fewer per step): a single list, no ghost rows, no particle sort due before the forces
-        lists = []
-        for f in integ.forces:
-            nl_f = getattr(f, "nlist", None)
-            if nl_f is not None and all(nl_f is not x for x in lists):
-                lists.append(nl_f)
-        fuse_list = lists[0] if (len(lists) == 1 and self.domain is None and hasattr(lists[0], "reserve_check")) else None
-
         def point_at_state():
             # (the arrays are replaced when particles migrate between ranks or are re-sorted)
             a.d_pos = st.pos.data_ptr()
@@ -231,19 +222,6 @@ class Simulation:
             a.d_net_force = st.net_force.data_ptr()
             a.d_image = st.image.data_ptr()
             a.N = st.N
-            a.d_pos_at_build = None
-            a.d_check_flag = None
-
-        def fused_check():
-            nl = fuse_list
-            if nl is None or not nl.built or st.n_ghost or nl._pos_at_build.shape[0] != st.N:
-                return None
-            if nl._built_consumer_version != nl._consumer_version or getattr(st, "order_generation", 0) != getattr(nl, "_order_generation", 0):
-                return None
-            r = nl.reserve_check(st)
-            a.d_pos_at_build, a.max_dist_sq = r["pos0_ptr"], r["max_dist_sq"]
-            a.d_check_flag, a.d_check_max_bits, a.d_check_disp = r["flag_ptr"], r["bits_ptr"], r["disp_ptr"]
-            return r
 
         def rotational_step(one):
             torque = net_torque()  # kept alive until the kernel is queued
@@ -266,7 +244,6 @@ class Simulation:
             # nothing reads the velocities between step two of one step and step one of the next: they are one
             # kernel (same arithmetic, one pass over the arrays); the last step two comes after the loop
             point_at_state()
-            reserved = fused_check()
             if k == 0:
                 _lib.check(lib.azp_integrate_nve_step_one(C.byref(a), stream), "azp_integrate_nve_step_one")
             else:
@@ -278,8 +255,6 @@ class Simulation:
             if self.domain is not None:
                 self.domain.exchange(self._halo_fields())  # ghost rows follow their owners' particles
             st.position_generation += 1
-            if reserved is not None:
-                fuse_list.check_was_queued(st, reserved)
             self.timestep += 1
             # re-index the particles between the position update and the force
             # evaluation: every per-particle array that survives the step is permuted,

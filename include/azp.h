@@ -541,14 +541,6 @@ typedef struct azp_nve_args
     double dt;
     uint32_t N;
     uint32_t block_size;
-    /* optional, step one (and step two + one): the neighbor list's distance check in the same pass over the positions
-     * (what azp_nlist_displacements computes, for the N particles of this call: a state without ghost rows). All NULL / 0:
-     * no check. */
-    const double* d_pos_at_build;          /* N x 4: positions when the list was built            */
-    double max_dist_sq;                    /* (r_buff / 2)^2                                      */
-    uint32_t* d_check_flag;                /* set to 1 when a particle moved farther              */
-    unsigned long long* d_check_max_bits;  /* atomic max of the bits of max |dx|^2                */
-    float* d_check_disp;                   /* N per-particle displacements, rounded up (may be NULL) */
     } azp_nve_args;
 
 int azp_integrate_nve_step_one(const azp_nve_args* args, void* stream);
