@@ -5,7 +5,7 @@
 HIP for gfx950, C ABI in ``include/azp.h``); there is no CPU fallback.
 """
 
-from . import _lib, bond, external, nlist, pair, sorter, synthetic
+from . import _lib, bond, external, nlist, pair, sorter, synthetic, tune
 from ._lib import AzpError
 from .simulation import All, ConstantVolume, Integrator, Simulation
 from .sorter import ParticleSorter
@@ -14,4 +14,4 @@ from .state import (Box, Snapshot, State, bonded_two_particle_snapshot, lattice_
 __version__ = "0.1.0"
 
 __all__ = ["All", "AzpError", "Box", "ParticleSorter", "ConstantVolume", "Integrator", "Simulation", "Snapshot", "State", "bond", "external", "nlist",
-           "pair", "synthetic", "two_particle_snapshot", "bonded_two_particle_snapshot", "lattice_snapshot"]
+           "pair", "synthetic", "tune", "two_particle_snapshot", "bonded_two_particle_snapshot", "lattice_snapshot"]

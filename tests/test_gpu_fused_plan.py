@@ -579,3 +579,30 @@ def test_native_binning_is_the_stable_sort(oracle):
     if cell_of is not None:
         assert np.array_equal(c.view(np.uint32), cell_of)
     assert np.bincount(c, minlength=ncell).max() > 500  # the crowded cell was really there
+
+
+def test_neighbor_list_buffer_tuner(oracle):
+    """azplugins_amd.tune.NeighborListBuffer (hoomd.md.tune.NeighborListBuffer reduced): sweeps the buffer through short
+    stretches of the run, leaves the fastest one set -- and the forces on the state it leaves behind are the oracle's."""
+    import azplugins_amd as azp
+
+    cfg = syn.config_plj_sc(12)
+    sim = azp.Simulation(device="cuda:0", seed=1)
+    sim.create_state_from_snapshot(azp.Snapshot.from_arrays(cfg["xyz"], cfg["L"]))
+    nl = azp.nlist.Cell(buffer=0.4)
+    pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=2.5, mode="shift")
+    pot.params[("A", "A")] = cfg["params"]
+    sim.operations.integrator = azp.Integrator(dt=0.004, forces=[pot], methods=[azp.ConstantVolume()])
+    sim.operations.tuners.clear()
+    sim.run(0)
+    sim.thermalize_particle_momenta(1.0, seed=3)
+    tuner = azp.tune.NeighborListBuffer(nl, candidates=(0.3, 0.5, 0.7), steps=12)
+    best = tuner.tune(sim)
+    assert best in (0.3, 0.5, 0.7) and nl.buffer == best and set(tuner.results) == {0.3, 0.5, 0.7}
+    sim.run(5)
+    n = sim.state.N
+    pos = sim.state.pos[:n].cpu().numpy()
+    box = oracle.make_box(cfg["L"])
+    onl = oracle.build_nlist(pos, box, 2.5)
+    f_ref = oracle.pair_forces(PLJ, pos, box, onl, oracle.pack_pair_params(PLJ, cfg["params"]), 2.5, 0.0, "shift")
+    assert_close(np.c_[pot.forces, pot.energies], f_ref)

@@ -23,6 +23,7 @@ ap.add_argument("--ncell", type=int, default=64)
 ap.add_argument("--no-plan", action="store_true")
 ap.add_argument("--sort-period", type=int, default=200, help="re-index the particles every this many steps (0 = never)")
 ap.add_argument("--curve", default="hilbert", help="particle sorter: hilbert | blocks")
+ap.add_argument("--tune-buffer", action="store_true", help="let azplugins_amd.tune.NeighborListBuffer pick the neighbor-list buffer first")
 ap.add_argument("--workload", default="ns", help="ns: the north-star liquid (PerturbedLJ); c3: BASELINE configs[2], 32,768 chains of 32 beads, "
                                                  "PerturbedLJ + DoubleWell bonds")
 ap.add_argument("--buffer", type=float, default=None, help="neighbor-list buffer r_buff (default: the workload's 0.4; HOOMD users tune it)")
@@ -58,6 +59,10 @@ sim.run(0)
 if args.workload != "c4":
     sim.thermalize_particle_momenta(args.kT, seed=7)
 sim.run(50)  # melt the lattice a little, warm the allocator
+if args.tune_buffer:
+    tuner = azp.tune.NeighborListBuffer(nl)
+    best = tuner.tune(sim)
+    print("NeighborListBuffer: steps/s by buffer %s -> buffer %.2f" % ({k: round(v) for k, v in tuner.results.items()}, best))
 torch.cuda.synchronize()
 b0 = nl.num_builds
 e0 = sum(f.energy for f in forces) + 0.5 * float((sim.state.vel[:N, 3] * (sim.state.vel[:N, :3] ** 2).sum(1)).sum())
