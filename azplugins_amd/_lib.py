@@ -184,7 +184,7 @@ class NlistArgs(C.Structure):
         ("box", Box),
         ("grid", CellGrid),
         ("ntypes", C.c_uint32),
-        ("_pad", C.c_uint32),
+        ("cell_subdivision", C.c_uint32),
         ("d_rlistsq", C.c_void_p),
         ("d_cell_of", C.c_void_p),
         ("d_cell_sorted", C.c_void_p),

@@ -158,6 +158,63 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(uint32_t ncell, uint32_t
         cell_start[ncell] = carry;
     }
 
+// The same scan for grids of many cells (half-width cells: 2^18 at N = 2^20), where one workgroup's 64 dependent trips
+// would take longer than the rest of the binning: every workgroup scans 4,096 cells on its own and leaves its total,
+// one workgroup scans the totals, a third pass adds them in.
+__global__ void __launch_bounds__(1024) bin_scan_local_kernel(uint32_t ncell, const uint32_t* __restrict__ count, uint32_t* __restrict__ cell_start,
+                                                              uint32_t* __restrict__ block_total)
+    {
+    __shared__ uint32_t s_wave[16];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t c = blockIdx.x * 4096u + 4u * t;
+    uint32_t v[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k)
+        v[k] = (c + k < ncell) ? count[c + k] : 0u;
+    const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+    uint32_t incl = mine;
+    for (int off = 1; off < 64; off <<= 1)
+        {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+        if ((int)lane >= off)
+            incl += up;
+        }
+    if (lane == 63u)
+        s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t w = 0; w < 16u; ++w)
+        {
+        const uint32_t x = s_wave[w];
+        before += (w < wave) ? x : 0u;
+        total += x;
+        }
+    uint32_t acc = before + incl - mine;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k)
+        {
+        if (c + k < ncell)
+            cell_start[c + k] = acc;
+        acc += v[k];
+        }
+    if (t == 0)
+        block_total[blockIdx.x] = total;
+    }
+
+__global__ void __launch_bounds__(256) bin_scan_add_kernel(uint32_t ncell, const uint32_t* __restrict__ block_start, uint32_t* __restrict__ count,
+                                                           uint32_t* __restrict__ cell_start)
+    {
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c < ncell)
+        {
+        const uint32_t v = cell_start[c] + block_start[c >> 12];
+        cell_start[c] = v;
+        count[c] = v;
+        }
+    else if (c == ncell)
+        cell_start[ncell] = block_start[(ncell + 4095u) >> 12]; // (the scan of the totals leaves the grand total behind the last)
+    }
+
 __global__ void __launch_bounds__(256) bin_scatter_kernel(uint32_t n_total, const uint32_t* __restrict__ cell_of,
                                                           uint32_t* __restrict__ cursor, uint32_t* __restrict__ order_tmp)
     {
@@ -193,6 +250,43 @@ __global__ void __launch_bounds__(256) bin_sort_cells_kernel(uint32_t ncell, con
             }
         if (k < n)
             order[b + rank] = mine;
+        }
+    }
+
+// The same for grids of small cells (a few particles each: half-width cells): one THREAD per cell, the cell's entries
+// ranked in registers (up to eight; longer cells straight from memory).
+__global__ void __launch_bounds__(256) bin_sort_small_cells_kernel(uint32_t ncell, const uint32_t* __restrict__ cell_start,
+                                                                   const uint32_t* __restrict__ order_tmp, uint32_t* __restrict__ order)
+    {
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= ncell)
+        return;
+    const uint32_t b = cell_start[c], n = cell_start[c + 1] - b;
+    if (n <= 8u)
+        {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k)
+            v[k] = (k < n) ? order_tmp[b + k] : 0xffffffffu;
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k)
+            {
+            uint32_t rank = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 8u; ++q)
+                rank += (v[q] < v[k]) ? 1u : 0u;
+            if (k < n)
+                order[b + rank] = v[k];
+            }
+        return;
+        }
+    for (uint32_t k = 0; k < n; ++k)
+        {
+        const uint32_t mine = order_tmp[b + k];
+        uint32_t rank = 0;
+        for (uint32_t q = 0; q < n; ++q)
+            rank += (order_tmp[b + q] < mine) ? 1u : 0u;
+        order[b + rank] = mine;
         }
     }
 
@@ -537,12 +631,26 @@ extern "C" int azp_nlist_bin(const azp_nlist_args* args, uint32_t* d_cursor, uin
     if (n)
         hipLaunchKernelGGL(bin_assign_count_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, n, args->d_pos, make_grid_dev(args->grid),
                            args->d_cell_of, d_cursor);
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, s, ncell, d_cursor, args->d_cell_start);
+    const uint32_t nblk = (ncell + 4095u) / 4096u;
+    if (nblk > 8u && nblk + 1u <= n)
+        {
+        // (the totals live in d_order_tmp, which the scatter fills only afterwards; bin_scan_kernel turns n totals into
+        // their n starts + the grand total at [n])
+        hipLaunchKernelGGL(bin_scan_local_kernel, dim3(nblk), dim3(1024), 0, s, ncell, d_cursor, args->d_cell_start, d_order_tmp);
+        hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, s, nblk, d_order_tmp, d_order_tmp);
+        hipLaunchKernelGGL(bin_scan_add_kernel, dim3((ncell + 1u + 255u) / 256u), dim3(256), 0, s, ncell, d_order_tmp, d_cursor, args->d_cell_start);
+        }
+    else
+        hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, s, ncell, d_cursor, args->d_cell_start);
     if (n)
         {
         hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, n, args->d_cell_of, d_cursor, d_order_tmp);
-        hipLaunchKernelGGL(bin_sort_cells_kernel, dim3((ncell + 3u) / 4u), dim3(256), 0, s, ncell, args->d_cell_start, d_order_tmp,
-                           const_cast<uint32_t*>(args->d_order));
+        if ((uint64_t)n <= 6ull * ncell)
+            hipLaunchKernelGGL(bin_sort_small_cells_kernel, dim3((ncell + 255u) / 256u), dim3(256), 0, s, ncell, args->d_cell_start, d_order_tmp,
+                               const_cast<uint32_t*>(args->d_order));
+        else
+            hipLaunchKernelGGL(bin_sort_cells_kernel, dim3((ncell + 3u) / 4u), dim3(256), 0, s, ncell, args->d_cell_start, d_order_tmp,
+                               const_cast<uint32_t*>(args->d_order));
         }
     return (int)hipGetLastError();
     }
@@ -566,6 +674,8 @@ static int nlist_scan(const azp_nlist_args* args, void* stream, bool fill)
         return AZP_ERROR_INVALID_ARGUMENT;
     if (fill ? (!args->d_head_list || !args->d_nlist) : !args->d_n_neigh)
         return AZP_ERROR_INVALID_ARGUMENT;
+    if (args->cell_subdivision > 1)
+        return AZP_ERROR_INVALID_ARGUMENT; // the 27-cell search needs cells as wide as the list radius
     if (fill && args->row_capacity && (!args->d_n_neigh || !args->d_max_neigh))
         return AZP_ERROR_INVALID_ARGUMENT;
     if (args->N == 0)

@@ -657,8 +657,8 @@ static int plan_build_tpp(PairPlan& p, const azp_pair_args& args, uint32_t tpp, 
     AZP_HIP_TRY(ensure(p.d_slice_Kend, p.cap_kend, (PLAN_SHELLS + 1) * (size_t)p.n_slices));
     AZP_HIP_TRY(ensure(p.d_slice_head, cap_heads_s, p.n_slices));
     AZP_HIP_TRY(ensure(p.d_slice_Kphase, p.cap_kphase, 2 * (size_t)p.n_slices));
-    size_t cap_flags = p.d_flags ? 8 : 0;
-    AZP_HIP_TRY(ensure(p.d_flags, cap_flags, 8));
+    size_t cap_flags = p.d_flags ? 16 : 0; // (16 words: pair_plan_cells.hip shares the buffer)
+    AZP_HIP_TRY(ensure(p.d_flags, cap_flags, 16));
     AZP_HIP_TRY(hipMemsetAsync(p.d_flags, 0, 8 * sizeof(uint32_t), s));
 
     PlanKArgs k;

@@ -38,6 +38,7 @@
 // particles per tile; rows longer than the row capacity (reported back so that the caller
 // retries with longer rows, HOOMD's own protocol for its list); tilted boxes.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -66,6 +67,14 @@ constexpr uint32_t PC_ROWMAX = 512;     // largest row capacity + 8 (PLAN_ROWBUF
 constexpr uint32_t PC_EMPTY = 0xffffffffu;
 constexpr uint32_t PC_CTAB = 1024;      // bins of the r^2 -> class table (one particle type)
 constexpr uint32_t PC_WALK = 8;         // raw-row entries a thread has in flight in the row walks (latency-bound otherwise; 16 buys nothing more)
+// Half-width cells (cells of width >= r_list / 2, azp_nlist_args.cell_subdivision = 2): the 5 x 5 x 5 cells around a member's
+// own hold 15.6 r_list^3 instead of 27, and with cells that small it pays to cut the search per MEMBER: a row of cells
+// (fixed y, z) farther from the member than r_list is skipped, the others are clipped along x to the cells the sphere
+// reaches -- 84 of the 125 cells on average, 0.39 x the candidate tests of the full-width form. The tile's cells are a
+// dense local grid (the members' cells + 2 on every side, at most PC_MAXGRID of them): no hash sets, no sort.
+constexpr uint32_t PC_BATCH_H = 768;    // candidates staged at a time
+constexpr uint32_t PC_MAXGRID = 2048;   // cells of a tile's local grid
+constexpr uint32_t PC_RUNS_H = 25;      // 5 x 5 rows of cells, one run of candidates each
 
 struct PlanCellsKArgs
     {
@@ -98,6 +107,8 @@ struct PlanCellsKArgs
     uint32_t row_cap;       // multiple of 8
     uint32_t stage_stride;
     uint32_t stop_after;    // AZP_PLAN_CELLS_PROFILE builds only (tools/plan_cells_probe.py): leave after this phase
+    double glo[3], gwinv[3]; // half-width cells: the grid's lower corner, 1 / cell width
+    float gw[3];             // cell widths
     };
 
 // Distinct coordinates of the cells next to cell c along one axis, ascending: c - 1, c, c + 1
@@ -153,18 +164,32 @@ __device__ __forceinline__ uint32_t pair_class(float rsq, float rcsq_m, float ri
     return !(rsq >= rcsq_m) ? ((rsq < rin) ? PLAN_CLS_CORE : PLAN_CLS_NEAR) : shell;
     }
 
-template<bool SINGLE> // SINGLE: one particle type (cutoffs are constants, classes come from a table)
+// SINGLE: one particle type (cutoffs are constants, classes come from a table). HALF: cells of half the list radius
+// (local grid, per-member runs); else cells of the full list radius (27 cells around each member cell).
+template<bool SINGLE, bool HALF>
 __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsKArgs a)
     {
     // One region, reused. Phase 0: hash sets + unsorted cells. Phase 2: the candidates of the
     // current batch (x, y, z, particle index; 16 B) + their types. Phases 3, 4: candidate -> slot.
-    // The per-thread class counters / cursors live behind it through phases 2 .. 4.
-    constexpr uint32_t CSTRIDE = PC_BATCH + 2;                  // one pad entry: candidates are read two at a time
-    constexpr uint32_t CAND_BYTES = CSTRIDE * 16 + PC_BATCH + 32; // x | y | z | particle index | types
-    constexpr uint32_t CUR_OFF = CAND_BYTES;
-    constexpr uint32_t REGION = CUR_OFF + PLAN_CLASSES * PC_THREADS * 2; // + 5,120 = 22,592
-    static_assert(CAND_BYTES >= 2 * PC_MAXCAND, "slot table does not fit");
-    static_assert(CAND_BYTES >= (PC_SETA + PC_SETB + PC_MAXCELLS) * 4, "hash sets do not fit");
+    // Full-width cells: the per-thread class counters / cursors live behind it through phases 2 .. 4.
+    // Half-width cells: the per-thread run tables and the prefix of the local grid's cell populations sit behind the
+    // batch; counters, bitmap and slot table take the place of batch and run tables once the tests are done.
+    constexpr uint32_t BATCH = HALF ? PC_BATCH_H : PC_BATCH;
+    constexpr uint32_t CSTRIDE = BATCH + 2;                  // one pad entry: candidates are read two at a time
+    constexpr uint32_t CAND_BYTES = (CSTRIDE * 16 + BATCH + 32 + 15) / 16 * 16; // x | y | z | particle index | types
+    constexpr uint32_t CUR_BYTES = PLAN_CLASSES * PC_THREADS * 2;
+    constexpr uint32_t RUNG_OFF = CAND_BYTES;                                  // HALF: u16 [run][thread], first candidate
+    constexpr uint32_t RUNL_OFF = RUNG_OFF + PC_RUNS_H * PC_THREADS * 2;       // HALF: u8 [run][thread], candidates in the run
+    constexpr uint32_t PRE_OFF = RUNL_OFF + PC_RUNS_H * PC_THREADS;            // HALF: u16 [PC_MAXGRID + 1] candidates before each cell
+    constexpr uint32_t CUR_OFF = HALF ? 2 * PC_MAXCAND : CAND_BYTES;
+    constexpr uint32_t USED_OFF = CUR_OFF + CUR_BYTES;                         // HALF: bitmap, word bases, sort keys of balanced plans
+    constexpr uint32_t WBASE_OFF = USED_OFF + PC_MAXCAND / 8;
+    constexpr uint32_t KEY_OFF = WBASE_OFF + (PC_MAXCAND / 32 + 4) * 4;
+    constexpr uint32_t REGION = HALF ? PRE_OFF + (PC_MAXGRID + 8) * 2 : CUR_OFF + CUR_BYTES; // 22,592 (full) / 36,448 (half)
+    static_assert(HALF || CAND_BYTES >= 2 * PC_MAXCAND, "slot table does not fit");
+    static_assert(HALF || CAND_BYTES >= (PC_SETA + PC_SETB + PC_MAXCELLS) * 4, "hash sets do not fit");
+    static_assert(!HALF || KEY_OFF + PC_THREADS * 4 <= PRE_OFF, "half-width cells: the late tables overlap the grid prefix");
+    static_assert(!HALF || PC_MAXGRID * 4 + 512 <= CAND_BYTES, "half-width cells: scan scratch does not fit");
     __shared__ __attribute__((aligned(16))) unsigned char s_region[REGION];
     float* cx = reinterpret_cast<float*>(s_region);
     float* cy = cx + CSTRIDE;
@@ -176,13 +201,22 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
     uint32_t* s_tmp = setB + PC_SETB;
     uint16_t* s_slot = reinterpret_cast<uint16_t*>(s_region);
     uint16_t* s_cur = reinterpret_cast<uint16_t*>(s_region + CUR_OFF); // [class][thread]
-    __shared__ uint32_t s_used[PC_MAXCAND / 32];
-    __shared__ uint32_t s_wordbase[PC_MAXCAND / 32 + 1];
+    __shared__ uint32_t s_used_f[HALF ? 1 : PC_MAXCAND / 32];
+    __shared__ uint32_t s_wordbase_f[HALF ? 1 : PC_MAXCAND / 32 + 1];
+    uint32_t* s_used = HALF ? reinterpret_cast<uint32_t*>(s_region + USED_OFF) : s_used_f;
+    uint32_t* s_wordbase = HALF ? reinterpret_cast<uint32_t*>(s_region + WBASE_OFF) : s_wordbase_f;
     uint32_t* s_cells = reinterpret_cast<uint32_t*>(s_region + 8192); // phase 1 only: the cells in ascending order
-    static_assert(8192 + PC_MAXCELLS * 4 <= CAND_BYTES, "sorted cells do not fit");
-    __shared__ uint32_t s_cfirst[PC_MAXCELLS], s_coff[PC_MAXCELLS + 8];
-    __shared__ uint32_t s_mcl[PC_MAXMC];                // the distinct cells of the members
-    __shared__ uint32_t s_runs[PC_MAXMC][PC_RUNS];      // per member cell: candidate ranges, g0 | g1 << 16
+    static_assert(HALF || 8192 + PC_MAXCELLS * 4 <= CAND_BYTES, "sorted cells do not fit");
+    __shared__ uint32_t s_cfirst[HALF ? 1 : PC_MAXCELLS], s_coff[HALF ? 1 : PC_MAXCELLS + 8];
+    __shared__ uint32_t s_mcl[HALF ? 1 : PC_MAXMC];                // the distinct cells of the members
+    __shared__ uint32_t s_runs[HALF ? 1 : PC_MAXMC][PC_RUNS];      // per member cell: candidate ranges, g0 | g1 << 16
+    uint16_t* s_rung = reinterpret_cast<uint16_t*>(s_region + RUNG_OFF);
+    unsigned char* s_runl = s_region + RUNL_OFF;
+    uint16_t* s_pre = reinterpret_cast<uint16_t*>(s_region + PRE_OFF);
+    uint32_t* s_need = reinterpret_cast<uint32_t*>(s_region);                       // HALF, phases 0-1: cells some member reaches
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_region + 512);                  // HALF, phase 1: population of the needed cells
+    __shared__ int s_glo[3], s_ghi[3];
+    __shared__ uint32_t s_wtot[4];
     __shared__ unsigned char s_ctab[SINGLE ? PC_CTAB : 4];
     __shared__ uint32_t s_kend[4][PLAN_SHELLS + 1], s_smax[4], s_kcore[4], s_ksure[4];
     __shared__ float s_rcutsq[64], s_rinnersq[64], s_rcw[64], s_rlistsq[64];
@@ -233,10 +267,23 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
         s_nmc = 0;
         s_cmax = 0;
         }
-    for (uint32_t t = tid; t < PC_MAXCAND / 32; t += PC_THREADS)
-        s_used[t] = 0;
-    for (uint32_t t = tid; t < PC_SETA + PC_SETB; t += PC_THREADS)
-        setA[t] = PC_EMPTY;
+    if (!HALF)
+        {
+        for (uint32_t t = tid; t < PC_MAXCAND / 32; t += PC_THREADS)
+            s_used[t] = 0;
+        for (uint32_t t = tid; t < PC_SETA + PC_SETB; t += PC_THREADS)
+            setA[t] = PC_EMPTY;
+        }
+    else
+        {
+        if (tid < 3)
+            {
+            s_glo[tid] = 0x7fffffff;
+            s_ghi[tid] = -0x7fffffff;
+            }
+        for (uint32_t t = tid; t < PC_MAXGRID / 32; t += PC_THREADS)
+            s_need[t] = 0;
+        }
     if (!SINGLE && rc_cached && tid < ntp)
         {
         s_rcutsq[tid] = (float)a.rcutsq[tid] * 1.0001f;
@@ -249,6 +296,16 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
     __syncthreads();
     float xi = 0.f, yi = 0.f, zi = 0.f;
     uint32_t mytype = 0, mycell = 0;
+    int hd[3] = {0, 0, 0};          // half-width cells: my cell relative to the first member's
+    float rel[3] = {0.f, 0.f, 0.f}; // and my position inside it, in cell widths
+    int rcell[3] = {0, 0, 0};
+    if (HALF)
+        {
+        const uint32_t c0 = a.cell_of[first];
+        rcell[0] = (int)(c0 % (uint32_t)dimx);
+        rcell[1] = (int)((c0 / (uint32_t)dimx) % (uint32_t)dimy);
+        rcell[2] = (int)(c0 / (uint32_t)(dimx * dimy));
+        }
     if (member)
         {
         const double4 p = load_scalar4(a.pos, i);
@@ -266,94 +323,288 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
         atomicMax(&s_cmax, (uint32_t)__float_as_int(fmaxf(fabsf(xi), fmaxf(fabsf(yi), fabsf(zi))))); // (positive floats order as integers)
         mytype = (uint32_t)type_from_w(p.w);
         mycell = a.cell_of[i];
-        if (set_insert(setA, PC_SETA, mycell) == 1u)
+        if constexpr (HALF)
             {
-            // first member seen in this cell: its neighbor cells join the tile's cell set
-            const uint32_t imc = atomicAdd(&s_nmc, 1u);
-            if (imc < PC_MAXMC)
-                s_mcl[imc] = mycell;
-            const int ccx = (int)(mycell % (uint32_t)dimx), ccy = (int)((mycell / (uint32_t)dimx) % (uint32_t)dimy), ccz = (int)(mycell / (uint32_t)(dimx * dimy));
-            int nzs[3], nys[3], nxs[3];
-            const int cz_n = axis_neighbors(ccz, dimz, a.periodic[2], nzs), cy_n = axis_neighbors(ccy, dimy, a.periodic[1], nys);
-            const int cx_n = axis_neighbors(ccx, dimx, a.periodic[0], nxs);
-            for (int qz = 0; qz < 3; ++qz)
-                for (int qy = 0; qy < 3; ++qy)
-                    for (int qx = 0; qx < 3; ++qx)
-                        {
-                        if (qz >= cz_n || qy >= cy_n || qx >= cx_n || imc >= PC_MAXMC || *(volatile uint32_t*)&s_ncells > PC_MAXCELLS)
-                            continue; // (beyond a limit: particles not sorted, stop filling the set)
-                        const uint32_t nc = (uint32_t)((nzs[qz] * dimy + nys[qy]) * dimx + nxs[qx]);
-                        const uint32_t r = set_insert(setB, PC_SETB, nc);
-                        if (r == 1u)
+            // my cell relative to the cell of the tile's first member (nearest image), my place inside it
+            const int cc[3] = {(int)(mycell % (uint32_t)dimx), (int)((mycell / (uint32_t)dimx) % (uint32_t)dimy), (int)(mycell / (uint32_t)(dimx * dimy))};
+            const double pk[3] = {p.x, p.y, p.z};
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                {
+                int d = cc[k] - rcell[k];
+                if (a.periodic[k])
+                    {
+                    const int half = a.dim[k] >> 1;
+                    d = (d > half) ? d - a.dim[k] : ((d < -half) ? d + a.dim[k] : d);
+                    }
+                hd[k] = d;
+                atomicMin(&s_glo[k], d);
+                atomicMax(&s_ghi[k], d);
+                const double u = (pk[k] - a.glo[k]) * a.gwinv[k];
+                const double r = a.periodic[k] ? u - floor(u) : u - (double)cc[k]; // (a clamped particle lies beyond its cell: taking the nearest point of the cell is the conservative side)
+                rel[k] = fminf(fmaxf((float)r, 0.f), 1.f);
+                }
+            }
+        else
+            {
+            if (set_insert(setA, PC_SETA, mycell) == 1u)
+                {
+                // first member seen in this cell: its neighbor cells join the tile's cell set
+                const uint32_t imc = atomicAdd(&s_nmc, 1u);
+                if (imc < PC_MAXMC)
+                    s_mcl[imc] = mycell;
+                const int ccx = (int)(mycell % (uint32_t)dimx), ccy = (int)((mycell / (uint32_t)dimx) % (uint32_t)dimy), ccz = (int)(mycell / (uint32_t)(dimx * dimy));
+                int nzs[3], nys[3], nxs[3];
+                const int cz_n = axis_neighbors(ccz, dimz, a.periodic[2], nzs), cy_n = axis_neighbors(ccy, dimy, a.periodic[1], nys);
+                const int cx_n = axis_neighbors(ccx, dimx, a.periodic[0], nxs);
+                for (int qz = 0; qz < 3; ++qz)
+                    for (int qy = 0; qy < 3; ++qy)
+                        for (int qx = 0; qx < 3; ++qx)
                             {
-                            const uint32_t idx = atomicAdd(&s_ncells, 1u);
-                            if (idx < PC_MAXCELLS)
-                                s_tmp[idx] = nc;
+                            if (qz >= cz_n || qy >= cy_n || qx >= cx_n || imc >= PC_MAXMC || *(volatile uint32_t*)&s_ncells > PC_MAXCELLS)
+                                continue; // (beyond a limit: particles not sorted, stop filling the set)
+                            const uint32_t nc = (uint32_t)((nzs[qz] * dimy + nys[qy]) * dimx + nxs[qx]);
+                            const uint32_t r = set_insert(setB, PC_SETB, nc);
+                            if (r == 1u)
+                                {
+                                const uint32_t idx = atomicAdd(&s_ncells, 1u);
+                                if (idx < PC_MAXCELLS)
+                                    s_tmp[idx] = nc;
+                                }
+                            else if (r == 2u)
+                                atomicAdd(&s_ncells, PC_MAXCELLS + 1u);
                             }
-                        else if (r == 2u)
-                            atomicAdd(&s_ncells, PC_MAXCELLS + 1u);
+                }
+        
+            }
+        }
+    __syncthreads();
+    uint32_t ncell_blk = 0, n_mc = 0, NC = 0;
+    // half-width cells: the tile's local grid (extent E, lower corner at cell gorg in unwrapped cell coordinates), my cell in it
+    int E[3] = {1, 1, 1}, gorg[3] = {0, 0, 0}, lc3[3] = {0, 0, 0};
+    uint32_t G = 0, nr = 0;
+    // local cell -> cell of the grid
+    auto cell_of_local = [&](uint32_t lc) -> uint32_t
+        {
+        const uint32_t t = lc / (uint32_t)E[0];
+        int u[3] = {gorg[0] + (int)(lc - t * (uint32_t)E[0]), gorg[1] + (int)(t % (uint32_t)E[1]), gorg[2] + (int)(t / (uint32_t)E[1])};
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            u[k] = (u[k] < 0) ? u[k] + a.dim[k] : ((u[k] >= a.dim[k]) ? u[k] - a.dim[k] : u[k]); // (periodic axes only leave the range, by dim / 2 + 2 <= dim at most)
+        return (uint32_t)((u[2] * dimy + u[1]) * dimx + u[0]);
+        };
+    // candidate number -> particle
+    auto cand_particle = [&](uint32_t g) -> uint32_t
+        {
+        if constexpr (HALF)
+            {
+            uint32_t sl = 0, sh = G; // last cell with pre[cell] <= g (empty and unused cells before it share its value)
+            while (sh - sl > 1)
+                {
+                const uint32_t mid = (sl + sh) >> 1;
+                if (s_pre[mid] <= g) sl = mid; else sh = mid;
+                }
+            return a.order[a.cell_start[cell_of_local(sl)] + (g - s_pre[sl])];
+            }
+        else
+            {
+            uint32_t sl = 0, sh = ncell_blk; // cell s with coff[s] <= g < coff[s + 1]
+            while (sh - sl > 1)
+                {
+                const uint32_t mid = (sl + sh) >> 1;
+                if (s_coff[mid] <= g) sl = mid; else sh = mid;
+                }
+            return a.order[s_cfirst[sl] + (g - s_coff[sl])];
+            }
+        };
+    if constexpr (HALF)
+        {
+        // ---- phase 1 (half-width cells): local grid, the cells each member reaches, candidate numbers, per-member runs ----
+        bool spread = false;
+        uint64_t cells = 1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            {
+            int lo = s_glo[k] - 2, hi = s_ghi[k] + 2;
+            if (!a.periodic[k])
+                {
+                lo = max(lo, -rcell[k]);
+                hi = min(hi, a.dim[k] - 1 - rcell[k]);
+                }
+            E[k] = hi - lo + 1;
+            gorg[k] = rcell[k] + lo;
+            lc3[k] = hd[k] - lo;
+            // (a tile that spans a whole periodic axis gets the cells at its ends twice, once on either side: two
+            // candidates for one particle, never both in the 5 cells one member looks at as long as the axis has 5)
+            spread = spread || (a.periodic[k] && a.dim[k] < 5) || E[k] > (int)PC_MAXGRID || E[k] < 1;
+            cells *= (uint64_t)max(E[k], 1);
+            }
+        if (spread || cells > PC_MAXGRID)
+            {
+            if (tid == 0)
+                {
+                atomicOr(&a.flags[1], 1u);
+                atomicMax(&a.flags[6], 4u); // members spread over too many cells: particles not spatially sorted (or a box of fewer than 5 cells)
+                a.tile_nstage[tile] = 0;
+                a.tile_head[tile] = (uint64_t)tile * a.stage_stride;
+                }
+            return;
+            }
+        G = (uint32_t)cells;
+        // the largest list radius (the cells are at least half as wide), with a margin far above the rounding of rel[]
+        float rlm = 0.f;
+        for (uint32_t t = 0; t < ntp; ++t)
+            rlm = fmaxf(rlm, (float)a.rlistsq[t]);
+        const float Rm2 = rlm * 1.0002f;
+        if (member)
+            {
+            // a row of cells (dy, dz) is searched if it comes within the list radius of ME, along x as far as the sphere reaches
+            for (uint32_t r = 0; r < PC_RUNS_H; ++r)
+                {
+                const int dz = (int)(r / 5u) - 2, dy = (int)(r % 5u) - 2;
+                const int yl = lc3[1] + dy, zl = lc3[2] + dz;
+                uint32_t byte = 0xffu;
+                if (yl >= 0 && yl < E[1] && zl >= 0 && zl < E[2])
+                    {
+                    const float fy = fmaxf(0.f, fmaxf((float)dy - rel[1], rel[1] - (float)(dy + 1))) * a.gw[1];
+                    const float fz = fmaxf(0.f, fmaxf((float)dz - rel[2], rel[2] - (float)(dz + 1))) * a.gw[2];
+                    const float d2 = fy * fy + fz * fz;
+                    if (d2 <= Rm2)
+                        {
+                        const float h = sqrtf(Rm2 - d2) * (float)a.gwinv[0];
+                        int xlo = max(-2, (int)floorf(rel[0] - h)), xhi = min(2, (int)floorf(rel[0] + h));
+                        xlo = max(xlo, -lc3[0]);
+                        xhi = min(xhi, E[0] - 1 - lc3[0]);
+                        if (xlo <= xhi)
+                            {
+                            byte = (uint32_t)(xlo + 2) | ((uint32_t)(xhi + 2) << 3);
+                            const uint32_t b0 = (uint32_t)((zl * E[1] + yl) * E[0] + lc3[0] + xlo);
+                            const uint64_t m = ((1ull << (uint32_t)(xhi - xlo + 1)) - 1ull) << (b0 & 31u);
+                            atomicOr(&s_need[b0 >> 5], (uint32_t)m);
+                            if (m >> 32)
+                                atomicOr(&s_need[(b0 >> 5) + 1u], (uint32_t)(m >> 32));
+                            }
                         }
+                    }
+                s_runl[r * PC_THREADS + tid] = (unsigned char)byte;
+                }
             }
-        }
-    __syncthreads();
-    const uint32_t ncell_blk = s_ncells, n_mc = s_nmc;
-    if (ncell_blk > PC_MAXCELLS || n_mc > PC_MAXMC)
-        {
-        if (tid == 0)
+        __syncthreads();
+        for (uint32_t lc = tid; lc < G; lc += PC_THREADS)
             {
-            atomicOr(&a.flags[1], 1u);
-            atomicMax(&a.flags[6], 4u); // members spread over too many cells: particles not spatially sorted
-            a.tile_nstage[tile] = 0;
-            a.tile_head[tile] = (uint64_t)tile * a.stage_stride;
+            uint32_t n = 0;
+            if ((s_need[lc >> 5] >> (lc & 31u)) & 1u)
+                {
+                const uint32_t c = cell_of_local(lc);
+                n = min(a.cell_start[c + 1] - a.cell_start[c], PC_MAXCAND + 1u);
+                }
+            s_cnt[lc] = n;
             }
-        return;
-        }
-    // ---- phase 1: the cells in ascending order, candidate ranges, the runs of every member cell ----
-    for (uint32_t t = tid; t < ncell_blk; t += PC_THREADS)
-        {
-        const uint32_t c = s_tmp[t];
-        uint32_t rank = 0;
-        for (uint32_t u = 0; u < ncell_blk; ++u)
-            rank += (s_tmp[u] < c) ? 1u : 0u;
-        const uint32_t f = a.cell_start[c];
-        s_cells[rank] = c;
-        s_cfirst[rank] = f;
-        s_coff[rank + 1] = a.cell_start[c + 1] - f;
-        }
-    __syncthreads();
-    if (tid < 64)
-        {
-        // inclusive scan of up to 512 counts, 8 per lane
-        constexpr uint32_t PER = PC_MAXCELLS / 64;
-        uint32_t v[PER], sum = 0;
+        __syncthreads();
+            {
+            // exclusive scan of the populations, eight cells per thread
+            constexpr uint32_t PER = PC_MAXGRID / PC_THREADS;
+            uint32_t v[PER], sum = 0;
 #pragma unroll
-        for (uint32_t q = 0; q < PER; ++q)
-            {
-            const uint32_t t = tid * PER + q;
-            v[q] = (t < ncell_blk) ? s_coff[t + 1] : 0u;
-            sum += v[q];
-            }
-        uint32_t incl = sum;
-        for (int off = 1; off < 64; off <<= 1)
-            {
-            const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
-            if ((int)lane >= off)
-                incl += up;
-            }
-        uint32_t acc = incl - sum;
+            for (uint32_t q = 0; q < PER; ++q)
+                {
+                const uint32_t t = tid * PER + q;
+                v[q] = (t < G) ? s_cnt[t] : 0u;
+                sum += v[q];
+                }
+            uint32_t incl = sum;
+            for (int off = 1; off < 64; off <<= 1)
+                {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+                if ((int)lane >= off)
+                    incl += up;
+                }
+            if (lane == 63)
+                s_wtot[wave] = incl;
+            __syncthreads();
+            uint32_t acc = incl - sum;
+            for (uint32_t w = 0; w < wave; ++w)
+                acc += s_wtot[w];
 #pragma unroll
-        for (uint32_t q = 0; q < PER; ++q)
-            {
-            const uint32_t t = tid * PER + q;
-            acc += v[q];
-            if (t < ncell_blk)
-                s_coff[t + 1] = acc;
+            for (uint32_t q = 0; q < PER; ++q)
+                {
+                const uint32_t t = tid * PER + q;
+                if (t <= G)
+                    s_pre[t] = (uint16_t)min(acc, 0xffffu); // (t == G: the total; more than PC_MAXCAND is refused below)
+                acc += v[q];
+                }
+            if (tid == PC_THREADS - 1u)
+                {
+                s_ncells = acc;
+                if (G == PC_MAXGRID)
+                    s_pre[G] = (uint16_t)min(acc, 0xffffu);
+                }
             }
-        if (tid == 0)
-            s_coff[0] = 0;
+        __syncthreads();
+        NC = s_ncells;
         }
-    __syncthreads();
-    const uint32_t NC = s_coff[ncell_blk];
+    else
+        {
+        ncell_blk = s_ncells;
+        n_mc = s_nmc;
+        if (ncell_blk > PC_MAXCELLS || n_mc > PC_MAXMC)
+            {
+            if (tid == 0)
+                {
+                atomicOr(&a.flags[1], 1u);
+                atomicMax(&a.flags[6], 4u); // members spread over too many cells: particles not spatially sorted
+                a.tile_nstage[tile] = 0;
+                a.tile_head[tile] = (uint64_t)tile * a.stage_stride;
+                }
+            return;
+            }
+        // ---- phase 1: the cells in ascending order, candidate ranges, the runs of every member cell ----
+        for (uint32_t t = tid; t < ncell_blk; t += PC_THREADS)
+            {
+            const uint32_t c = s_tmp[t];
+            uint32_t rank = 0;
+            for (uint32_t u = 0; u < ncell_blk; ++u)
+                rank += (s_tmp[u] < c) ? 1u : 0u;
+            const uint32_t f = a.cell_start[c];
+            s_cells[rank] = c;
+            s_cfirst[rank] = f;
+            s_coff[rank + 1] = a.cell_start[c + 1] - f;
+            }
+        __syncthreads();
+        if (tid < 64)
+            {
+            // inclusive scan of up to 512 counts, 8 per lane
+            constexpr uint32_t PER = PC_MAXCELLS / 64;
+            uint32_t v[PER], sum = 0;
+    #pragma unroll
+            for (uint32_t q = 0; q < PER; ++q)
+                {
+                const uint32_t t = tid * PER + q;
+                v[q] = (t < ncell_blk) ? s_coff[t + 1] : 0u;
+                sum += v[q];
+                }
+            uint32_t incl = sum;
+            for (int off = 1; off < 64; off <<= 1)
+                {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+                if ((int)lane >= off)
+                    incl += up;
+                }
+            uint32_t acc = incl - sum;
+    #pragma unroll
+            for (uint32_t q = 0; q < PER; ++q)
+                {
+                const uint32_t t = tid * PER + q;
+                acc += v[q];
+                if (t < ncell_blk)
+                    s_coff[t + 1] = acc;
+                }
+            if (tid == 0)
+                s_coff[0] = 0;
+            }
+        __syncthreads();
+        NC = s_coff[ncell_blk];
+        }
     if (NC > PC_MAXCAND)
         {
         if (tid == 0)
@@ -376,49 +627,93 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
     const float cmax = __int_as_float((int)s_cmax) + 2.f * (float)a.r_list_max;
     const float rl_extra = 1e-6f * (float)a.r_list_max * cmax;
     const float rl1 = SINGLE ? (a.rlistsq[0] > 0.0 ? (float)a.rlistsq[0] * 1.00001f + rl_extra : -1.f) : 0.f;
-    // the runs of a member cell: its 3 x 3 rows of cells along x; a row is one or two runs of consecutive
-    // cells, consecutive in the sorted cell array too (every one of them is in the set): one contiguous
-    // candidate range per run
-    for (uint32_t t = tid; t < n_mc * PC_RUNS; t += PC_THREADS)
+    if constexpr (HALF)
         {
-        const uint32_t imc = t / PC_RUNS, q = t % PC_RUNS;
-        const uint32_t mc = s_mcl[imc];
-        const int mcx = (int)(mc % (uint32_t)dimx), mcy = (int)((mc / (uint32_t)dimx) % (uint32_t)dimy), mcz = (int)(mc / (uint32_t)(dimx * dimy));
-        int nzs[3], nys[3], nxs[3];
-        const int cz_n = axis_neighbors(mcz, dimz, a.periodic[2], nzs), cy_n = axis_neighbors(mcy, dimy, a.periodic[1], nys);
-        const int cx_n = axis_neighbors(mcx, dimx, a.periodic[0], nxs);
-        int run0[2] = {0, 0}, runlen[2] = {0, 0};
-        int nruns = 0;
-        for (int k = 0; k < 3; ++k)
+        // my runs: the rows kept above, as candidate ranges (first candidate, length), empty ones dropped
+        if (member)
             {
-            if (k >= cx_n)
-                continue;
-            if (nruns && nxs[k] == run0[nruns - 1] + runlen[nruns - 1])
-                ++runlen[nruns - 1];
-            else
+            const int rowbase = (lc3[2] * E[1] + lc3[1]) * E[0] + lc3[0];
+            for (uint32_t r = 0; r < PC_RUNS_H; ++r)
                 {
-                run0[nruns] = nxs[k];
-                runlen[nruns] = 1;
-                ++nruns;
+                const uint32_t byte = s_runl[r * PC_THREADS + tid];
+                if (byte == 0xffu)
+                    continue;
+                const int dz = (int)(r / 5u) - 2, dy = (int)(r % 5u) - 2;
+                const int b = rowbase + (dz * E[1] + dy) * E[0];
+                const uint32_t g0 = s_pre[b + (int)(byte & 7u) - 2], g1 = s_pre[b + (int)(byte >> 3) - 1];
+                uint32_t len = g1 - g0;
+                if (len > 255u)
+                    {
+                    s_bad = 2; // a run of five cells holds more candidates than a byte counts: cells far denser than a liquid's
+                    len = 255u;
+                    }
+                if (len)
+                    {
+                    s_rung[nr * PC_THREADS + tid] = (uint16_t)g0;
+                    s_runl[nr * PC_THREADS + tid] = (unsigned char)len; // (nr <= r: behind the bytes still to be read)
+                    ++nr;
+                    }
                 }
             }
-        const int row = (int)(q >> 1), r = (int)(q & 1u);
-        const int qz = row / 3, qy = row % 3;
-        uint32_t packed = 0; // empty run
-        if (qz < cz_n && qy < cy_n && r < nruns)
+        __syncthreads();
+        if (s_bad)
             {
-            const int zz = qz == 0 ? nzs[0] : (qz == 1 ? nzs[1] : nzs[2]);
-            const int yy = qy == 0 ? nys[0] : (qy == 1 ? nys[1] : nys[2]);
-            const uint32_t c = (uint32_t)((zz * dimy + yy) * dimx + (r ? run0[1] : run0[0]));
-            uint32_t sl = 0, sh = ncell_blk; // s_cells[sl] == c (present by construction)
-            while (sh - sl > 1)
+            if (tid == 0)
                 {
-                const uint32_t mid = (sl + sh) >> 1;
-                if (s_cells[mid] <= c) sl = mid; else sh = mid;
+                atomicOr(&a.flags[1], 1u);
+                atomicMax(&a.flags[6], 5u);
+                a.tile_nstage[tile] = 0;
+                a.tile_head[tile] = (uint64_t)tile * a.stage_stride;
                 }
-            packed = s_coff[sl] | (s_coff[sl + (uint32_t)(r ? runlen[1] : runlen[0])] << 16); // NC <= 8192: 16 bits each
+            return;
             }
-        s_runs[imc][q] = packed;
+        }
+    else
+        {
+        // the runs of a member cell: its 3 x 3 rows of cells along x; a row is one or two runs of consecutive
+        // cells, consecutive in the sorted cell array too (every one of them is in the set): one contiguous
+        // candidate range per run
+        for (uint32_t t = tid; t < n_mc * PC_RUNS; t += PC_THREADS)
+            {
+            const uint32_t imc = t / PC_RUNS, q = t % PC_RUNS;
+            const uint32_t mc = s_mcl[imc];
+            const int mcx = (int)(mc % (uint32_t)dimx), mcy = (int)((mc / (uint32_t)dimx) % (uint32_t)dimy), mcz = (int)(mc / (uint32_t)(dimx * dimy));
+            int nzs[3], nys[3], nxs[3];
+            const int cz_n = axis_neighbors(mcz, dimz, a.periodic[2], nzs), cy_n = axis_neighbors(mcy, dimy, a.periodic[1], nys);
+            const int cx_n = axis_neighbors(mcx, dimx, a.periodic[0], nxs);
+            int run0[2] = {0, 0}, runlen[2] = {0, 0};
+            int nruns = 0;
+            for (int k = 0; k < 3; ++k)
+                {
+                if (k >= cx_n)
+                    continue;
+                if (nruns && nxs[k] == run0[nruns - 1] + runlen[nruns - 1])
+                    ++runlen[nruns - 1];
+                else
+                    {
+                    run0[nruns] = nxs[k];
+                    runlen[nruns] = 1;
+                    ++nruns;
+                    }
+                }
+            const int row = (int)(q >> 1), r = (int)(q & 1u);
+            const int qz = row / 3, qy = row % 3;
+            uint32_t packed = 0; // empty run
+            if (qz < cz_n && qy < cy_n && r < nruns)
+                {
+                const int zz = qz == 0 ? nzs[0] : (qz == 1 ? nzs[1] : nzs[2]);
+                const int yy = qy == 0 ? nys[0] : (qy == 1 ? nys[1] : nys[2]);
+                const uint32_t c = (uint32_t)((zz * dimy + yy) * dimx + (r ? run0[1] : run0[0]));
+                uint32_t sl = 0, sh = ncell_blk; // s_cells[sl] == c (present by construction)
+                while (sh - sl > 1)
+                    {
+                    const uint32_t mid = (sl + sh) >> 1;
+                    if (s_cells[mid] <= c) sl = mid; else sh = mid;
+                    }
+                packed = s_coff[sl] | (s_coff[sl + (uint32_t)(r ? runlen[1] : runlen[0])] << 16); // NC <= 8192: 16 bits each
+                }
+            s_runs[imc][q] = packed;
+            }
         }
     if (SINGLE)
         {
@@ -447,8 +742,9 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
         }
     // which member cell is mine
     uint32_t imc_mine = 0;
-    for (uint32_t u = 0; u < n_mc; ++u)
-        imc_mine = (s_mcl[u] == mycell) ? u : imc_mine;
+    if (!HALF)
+        for (uint32_t u = 0; u < n_mc; ++u)
+            imc_mine = (s_mcl[u] == mycell) ? u : imc_mine;
     const bool wide = s_wide != 0;
     const float bLx = (float)a.box.Lx, bLy = (float)a.box.Ly, bLz = (float)a.box.Lz;
     // (1 / L = 0 along a non-periodic axis: rint(0) = 0, nothing is subtracted)
@@ -471,22 +767,37 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
 
     // ---- phase 2: stage a batch of candidates; every thread walks its member's runs through it ----
     uint32_t cnt = 0;
-    for (uint32_t t = 0; t < PLAN_CLASSES; ++t)
-        s_cur[t * PC_THREADS + tid] = 0;
-    for (uint32_t b0 = 0; b0 < NC; b0 += PC_BATCH)
+    if (!HALF) // (half-width cells: the counters take the place of the run tables once the tests are done)
+        for (uint32_t t = 0; t < PLAN_CLASSES; ++t)
+            s_cur[t * PC_THREADS + tid] = 0;
+    // run q of my member: candidates [first, end)
+    auto fetch_run = [&](uint32_t q, uint32_t& first_c, uint32_t& end_c)
         {
-        const uint32_t nbat = min(PC_BATCH, NC - b0);
+        if constexpr (HALF)
+            {
+            first_c = s_rung[q * PC_THREADS + tid];
+            end_c = first_c + s_runl[q * PC_THREADS + tid];
+            }
+        else
+            {
+            const uint32_t packed = s_runs[imc_mine][q];
+            first_c = packed & 0xffffu;
+            end_c = packed >> 16;
+            }
+        };
+    const uint32_t n_runs = HALF ? nr : PC_RUNS;
+    uint32_t qres = 0; // my first run that reaches beyond the batches done so far
+#ifdef AZP_PLAN_CELLS_PROFILE
+    uint32_t prof_trips = 0, prof_tests = 0;
+#endif
+    for (uint32_t b0 = 0; b0 < NC; b0 += BATCH)
+        {
+        const uint32_t nbat = min(BATCH, NC - b0);
         __syncthreads(); // previous batch (first pass: the hash sets, the run table) settled
         for (uint32_t t = tid; t < nbat; t += PC_THREADS)
             {
             const uint32_t g = b0 + t;
-            uint32_t sl = 0, sh = ncell_blk; // cell s with coff[s] <= g < coff[s + 1]
-            while (sh - sl > 1)
-                {
-                const uint32_t mid = (sl + sh) >> 1;
-                if (s_coff[mid] <= g) sl = mid; else sh = mid;
-                }
-            const uint32_t j = a.order[s_cfirst[sl] + (g - s_coff[sl])];
+            const uint32_t j = cand_particle(g);
             const double4 pj = load_scalar4(a.pos, j);
             double x = pj.x - cref.x, y = pj.y - cref.y, z = pj.z - cref.z;
             if (a.box.px) x = __builtin_fma(-a.box.Lx, rint(x * a.box.Lxinv), x);
@@ -504,17 +815,33 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
             // single-precision math: one instruction per pair of differences / products)
             typedef float f2 __attribute__((ext_vector_type(2)));
             const f2 xi2 = {xi, xi}, yi2 = {yi, yi}, zi2 = {zi, zi};
-            uint32_t q = 0, g = 0, l1 = 0;
-            while (g >= l1 && q < PC_RUNS)
+            // (the runs ascend: one that starts behind the batch ends the walk, and the next batch resumes at the
+            // first run this one did not use up -- without that every lane trudges through its remaining runs at
+            // the end of every batch, each on its own trip of the wave)
+            uint32_t q = qres, g = 0, l1 = 0;
+            const uint32_t bend = b0 + nbat;
+            while (g >= l1 && q < n_runs)
                 {
-                const uint32_t packed = s_runs[imc_mine][q++];
-                g = max(packed & 0xffffu, b0);
-                l1 = min(packed >> 16, b0 + nbat);
+                uint32_t rf, re;
+                fetch_run(q, rf, re);
+                if (rf >= bend)
+                    {
+                    q = n_runs;
+                    break;
+                    }
+                qres = (re <= bend && qres == q) ? q + 1u : qres; // (an empty run behind one that reaches into the next batch must not step over it)
+                ++q;
+                g = max(rf, b0);
+                l1 = min(re, bend);
                 }
             while (g < l1)
                 {
                 const uint32_t gc = g, c = g - b0;
                 const bool second = gc + 1u < l1; // (else the pad entry / the next cell's first candidate: ignored)
+#ifdef AZP_PLAN_CELLS_PROFILE
+                ++prof_trips;
+                prof_tests += second ? 2u : 1u;
+#endif
                 const f2 X = {cx[c], cx[c + 1u]}, Y = {cy[c], cy[c + 1u]}, Z = {cz[c], cz[c + 1u]};
                 uint32_t tpa = 0, tpb = 0;
                 float rla = rl1, rlb = rl1;
@@ -528,11 +855,19 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
                     rlb = rlb > 0.f ? rlb + rl_extra : rlb;
                     }
                 g += 2u;
-                while (g >= l1 && q < PC_RUNS)
+                while (g >= l1 && q < n_runs)
                     {
-                    const uint32_t packed = s_runs[imc_mine][q++];
-                    g = max(packed & 0xffffu, b0);
-                    l1 = min(packed >> 16, b0 + nbat);
+                    uint32_t rf, re;
+                    fetch_run(q, rf, re);
+                    if (rf >= bend)
+                        {
+                        q = n_runs;
+                        break;
+                        }
+                    qres = (re <= bend && qres == q) ? q + 1u : qres; // (an empty run behind one that reaches into the next batch must not step over it)
+                    ++q;
+                    g = max(rf, b0);
+                    l1 = min(re, bend);
                     }
                 f2 dx = xi2 - X, dy = yi2 - Y, dz = zi2 - Z;
                 if (wide)
@@ -593,10 +928,41 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
                 }
             }
         }
+#ifdef AZP_PLAN_CELLS_PROFILE
+        {
+        // (tools/plan_cells_probe.py: candidate tests, trips of the slowest lane of every wave, candidates and grid cells per tile)
+        uint32_t tr = prof_trips, ts = prof_tests;
+        for (int off = 32; off > 0; off >>= 1)
+            {
+            tr = max(tr, (uint32_t)__shfl_xor((int)tr, off, 64));
+            ts += (uint32_t)__shfl_xor((int)ts, off, 64);
+            }
+        if (lane == 0)
+            {
+            atomicAdd(&a.flags[8], ts >> 4);
+            atomicAdd(&a.flags[9], tr);
+            }
+        if (tid == 0)
+            {
+            atomicAdd(&a.flags[10], NC);
+            atomicAdd(&a.flags[11], HALF ? G : ncell_blk);
+            atomicAdd(&a.flags[12], (NC + BATCH - 1u) / BATCH);
+            }
+        }
+#endif
     // every thread walks its raw row once: entries per class (the cursors of phase 4 start from these
     // totals) and the bitmap of the candidates somebody listed. Here and not in the loop above: all
     // lanes are busy, there only the accepting sixth was
     __syncthreads();
+    if (HALF)
+        {
+        // (batch and run tables are done with: counters and bitmap move in)
+        for (uint32_t t = 0; t < PLAN_CLASSES; ++t)
+            s_cur[t * PC_THREADS + tid] = 0;
+        for (uint32_t t = tid; t < PC_MAXCAND / 32; t += PC_THREADS)
+            s_used[t] = 0;
+        __syncthreads();
+        }
     if (member PC_PROFILE_AND(!(a.stop_after & 0x200u)))
         {
         const uint32_t nk = min(cnt, a.row_cap);
@@ -638,7 +1004,7 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
     uint32_t pos_in_tile = tid;
     if (a.perm)
         {
-        uint32_t* s_key = &s_runs[0][0]; // (the run table is not needed any more)
+        uint32_t* s_key = HALF ? reinterpret_cast<uint32_t*>(s_region + KEY_OFF) : &s_runs[0][0]; // (the run table is not needed any more)
         const uint32_t nin = member ? min((uint32_t)s_cur[tid] + (uint32_t)s_cur[PC_THREADS + tid] + (uint32_t)s_cur[2 * PC_THREADS + tid], 1023u) : 0u;
         const uint32_t key = ((1023u - nin) << 8) | tid;
         s_key[tid] = key;
@@ -708,13 +1074,7 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
             {
             const uint32_t slot = s_wordbase[g >> 5] + (uint32_t)__popc(w & (bit - 1u));
             s_slot[g] = (uint16_t)slot;
-            uint32_t sl = 0, sh = ncell_blk;
-            while (sh - sl > 1)
-                {
-                const uint32_t mid = (sl + sh) >> 1;
-                if (s_coff[mid] <= g) sl = mid; else sh = mid;
-                }
-            stage[slot] = a.order[s_cfirst[sl] + (g - s_coff[sl])];
+            stage[slot] = cand_particle(g);
             }
         }
     // class totals -> first row position of each class (the cursors of phase 4); chunk counts per class boundary
@@ -827,8 +1187,8 @@ int plan_build_from_cells(PairPlan& p, const azp_nlist_args& c, const azp_pair_a
     AZP_HIP_TRY(ensure_buf(p.d_slice_Kend, p.cap_kend, (PLAN_SHELLS + 1) * (size_t)p.n_slices));
     AZP_HIP_TRY(ensure_buf(p.d_slice_head, cap_heads_s, p.n_slices));
     AZP_HIP_TRY(ensure_buf(p.d_slice_Kphase, p.cap_kphase, 2 * (size_t)p.n_slices));
-    size_t cap_flags = p.d_flags ? 8 : 0;
-    AZP_HIP_TRY(ensure_buf(p.d_flags, cap_flags, 8));
+    size_t cap_flags = p.d_flags ? 16 : 0;
+    AZP_HIP_TRY(ensure_buf(p.d_flags, cap_flags, 16)); // (8 .. 15: counters of the profiling build)
     p.total_chunks = (uint64_t)p.n_slices * (row_cap / 8u);
     AZP_HIP_TRY(ensure_buf(p.d_cnl, p.cap_cnl, (size_t)p.total_chunks * 64));
     AZP_HIP_TRY(ensure_buf(p.d_raw, p.cap_raw, (size_t)p.n_tiles * 256u * row_cap));
@@ -871,27 +1231,40 @@ int plan_build_from_cells(PairPlan& p, const azp_nlist_args& c, const azp_pair_a
     k.n_tiles = p.n_tiles;
     k.row_cap = row_cap;
 #ifdef AZP_PLAN_CELLS_PROFILE
-    static const uint32_t stop_after = []() { const char* e = getenv("AZP_PLAN_CELLS_STOP"); return e ? (uint32_t)atoi(e) : 0u; }();
+    const char* stop_env = getenv("AZP_PLAN_CELLS_STOP"); // (read at every build: tools/plan_cells_probe.py sets it after its warm-up run)
+    const uint32_t stop_after = stop_env ? (uint32_t)atoi(stop_env) : 0u;
 #else
     const uint32_t stop_after = 0;
 #endif
     k.stop_after = stop_after;
+    const bool half = c.cell_subdivision == 2;
+    for (int q = 0; q < 3; ++q)
+        {
+        k.glo[q] = c.grid.lo[q];
+        k.gwinv[q] = 1.0 / c.grid.width[q];
+        k.gw[q] = (float)c.grid.width[q];
+        }
 
     uint32_t stride = p.stage_stride_hint;
     if (stride == 0)
         stride = ((uint64_t)p.n_tiles * (PLAN_MAX_STAGE + 1) * 4 <= (256ull << 20)) ? PLAN_MAX_STAGE + 1 : 1536;
-    uint32_t h_flags[8];
+    uint32_t h_flags[16];
     for (;;)
         {
         stride = std::min<uint32_t>((stride + 63u) & ~63u, PLAN_MAX_STAGE + 1);
         AZP_HIP_TRY(ensure_buf(p.d_stage_idx, p.cap_stage, (size_t)p.n_tiles * stride));
-        AZP_HIP_TRY(hipMemsetAsync(p.d_flags, 0, 8 * sizeof(uint32_t), s));
+        AZP_HIP_TRY(hipMemsetAsync(p.d_flags, 0, 16 * sizeof(uint32_t), s));
         k.stage_idx = p.d_stage_idx;
         k.stage_stride = stride;
-        if (c.ntypes == 1)
-            hipLaunchKernelGGL(plan_cells_kernel<true>, dim3((p.n_tiles + 7u) & ~7u), dim3(PC_THREADS), 0, s, k);
+        const dim3 grid((p.n_tiles + 7u) & ~7u), block(PC_THREADS);
+        if (c.ntypes == 1 && half)
+            hipLaunchKernelGGL((plan_cells_kernel<true, true>), grid, block, 0, s, k);
+        else if (c.ntypes == 1)
+            hipLaunchKernelGGL((plan_cells_kernel<true, false>), grid, block, 0, s, k);
+        else if (half)
+            hipLaunchKernelGGL((plan_cells_kernel<false, true>), grid, block, 0, s, k);
         else
-            hipLaunchKernelGGL(plan_cells_kernel<false>, dim3((p.n_tiles + 7u) & ~7u), dim3(PC_THREADS), 0, s, k);
+            hipLaunchKernelGGL((plan_cells_kernel<false, false>), grid, block, 0, s, k);
         AZP_HIP_TRY(hipGetLastError());
         AZP_HIP_TRY(hipMemcpyAsync(h_flags, p.d_flags, sizeof(h_flags), hipMemcpyDeviceToHost, s));
         p.h_tile_nstage.resize(p.n_tiles);
@@ -899,6 +1272,11 @@ int plan_build_from_cells(PairPlan& p, const azp_nlist_args& c, const azp_pair_a
         AZP_HIP_TRY(hipStreamSynchronize(s));
         p.max_stage = h_flags[2];
         p.max_row = h_flags[5];
+#ifdef AZP_PLAN_CELLS_PROFILE
+        fprintf(stderr, "plan_cells: %.1f candidate tests per particle, %.1f trips of the slowest lane per wave, per tile %.0f candidates, %.0f cells, %.2f batches\n",
+                16.0 * h_flags[8] / c.N, (double)h_flags[9] / (p.n_tiles * 4.0), (double)h_flags[10] / p.n_tiles, (double)h_flags[11] / p.n_tiles,
+                (double)h_flags[12] / p.n_tiles);
+#endif
         if (stop_after)
             {
             p.invalid_reason = 7; // profiling run: the kernel left early, nothing to use
@@ -941,7 +1319,9 @@ extern "C" int azp_pair_plan_build_from_cells(azp_pair_plan* plan, const azp_nli
         || !cells->d_n_neigh || !pair->d_rcutsq || cells->ntypes == 0 || cells->ntypes != pair->ntypes || cells->n_total < cells->N)
         return AZP_ERROR_INVALID_ARGUMENT;
     for (int k = 0; k < 3; ++k)
-        if (cells->grid.dim[k] == 0)
+        if (cells->grid.dim[k] == 0 || !(cells->grid.width[k] > 0.0))
             return AZP_ERROR_INVALID_ARGUMENT;
+    if (cells->cell_subdivision > 2)
+        return AZP_ERROR_INVALID_ARGUMENT;
     return azp::plan_build_from_cells(*reinterpret_cast<azp::PairPlan*>(plan), *cells, *pair, static_cast<hipStream_t>(stream));
     }

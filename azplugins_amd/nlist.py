@@ -124,7 +124,7 @@ class Cell(NeighborList):
     # (AZP_NATIVE_BINNING=1 turns it on): its five kernels take 63 us against the pipeline's ~130 us + launch gaps,
     # but a 300-step MD run of the north star came out SLOWER with it (0.49 vs 0.43 ms per step, twice each on one
     # box) for a reason the kernel trace does not show; kept for callers without the framework, tested for equality.
-    native_binning = os.environ.get("AZP_NATIVE_BINNING", "0") == "1"
+    native_binning = {"0": False, "1": True}.get(os.environ.get("AZP_NATIVE_BINNING", ""), None)  # None: when the cells number more than 2^16 (the framework sort then needs four radix passes)
 
     def compute(self, state, force=False, compact=False):
         """Rebuild only when needed (HOOMD's criterion): never built, forced, or some
@@ -261,50 +261,14 @@ class Cell(NeighborList):
         # orthorhombic frame only when untilted, so require orthorhombic here
         if box.is_triclinic:
             raise _lib.AzpError("Cell neighbor list: triclinic boxes are not supported yet")
-        for k in range(3):
-            dim = max(int(np.floor(L[k] / rl_max)), 1)
-            a.grid.dim[k] = dim
-            a.grid.width[k] = L[k] / dim
-            a.grid.lo[k] = -0.5 * L[k]
-            a.grid.periodic[k] = 1 if box.periodic[k] else 0
-        ncell = int(a.grid.dim[0]) * int(a.grid.dim[1]) * int(a.grid.dim[2])
         a.ntypes = ntypes
         rlistsq = torch.from_numpy(np.ascontiguousarray((rl * rl).reshape(-1))).to(dev)
         a.d_rlistsq = rlistsq.data_ptr()
         stream = torch.cuda.current_stream(dev).cuda_stream
-
-        cell_of = torch.empty(n_total, dtype=torch.int32, device=dev)
-        a.d_cell_of = cell_of.data_ptr()
-        if self.native_binning and n_total <= 128 * ncell:
-            # one libazp call (counting sort, stable in the particle index): five small kernels back to back instead
-            # of a framework sort pipeline of a dozen launches with host gaps between them (0.25 -> 0.05 ms per rebuild
-            # at N = 2^20). Cells that hold very many particles (tiny boxes) take the general path: the per-cell
-            # sort is quadratic in the cell's population.
-            order = torch.empty(n_total, dtype=torch.int32, device=dev)
-            cell_start = torch.empty(ncell + 1, dtype=torch.int32, device=dev)
-            cursor = torch.empty(ncell, dtype=torch.int32, device=dev)
-            order_tmp = torch.empty(n_total, dtype=torch.int32, device=dev)
-            a.d_order = order.data_ptr()
-            a.d_cell_start = cell_start.data_ptr()
-            _lib.check(l.azp_nlist_bin(C.byref(a), cursor.data_ptr(), order_tmp.data_ptr(), stream), "azp_nlist_bin")
-            cell_sorted = None
-            keep_bin = (cursor, order_tmp)
-        else:
-            _lib.check(l.azp_nlist_cell_assign(C.byref(a), stream), "azp_nlist_cell_assign")
-            if ncell <= 65536:
-                # 16-bit keys: two radix passes instead of four (0.06 instead of 0.16 ms at N = 2^20); same permutation
-                k16, order = torch.sort((cell_of - 32768).to(torch.int16), stable=True)
-                cell_sorted = k16.to(torch.int32) + 32768
-            else:
-                cell_sorted, order = torch.sort(cell_of, stable=True)
-        if cell_sorted is not None:
-            order = order.to(torch.int32)
-            cell_start = torch.empty(ncell + 1, dtype=torch.int32, device=dev)
-            a.d_cell_sorted = cell_sorted.data_ptr()
-            a.d_order = order.data_ptr()
-            a.d_cell_start = cell_start.data_ptr()
-            _lib.check(l.azp_nlist_cell_bounds(C.byref(a), stream), "azp_nlist_cell_bounds")
-            keep_bin = ()
+        self._rl_max, self._box_at_build = rl_max, box
+        self._fused_active = self._fused_eligible()
+        sub = 2 if (self._fused_active and self._half_cells_wanted(box, rl_max, n_total)) else 1
+        bins = self._bin(a, box, rl_max, n_total, sub, dev, stream)
 
         keep = []
         if "bond" in self.exclusions and state.bond_group.shape[0]:
@@ -318,10 +282,9 @@ class Cell(NeighborList):
         a.d_n_neigh = n_neigh.data_ptr()
         self.n_neigh = n_neigh
         self._cells = a
-        self._keep = (rlistsq, cell_of, cell_sorted, order, cell_start, keep, keep_bin)
+        self._keep = (rlistsq, bins, keep)
         self._pos_at_build = state.pos[:n_total].clone()
         self._nlist, self._head_list, self._size = None, None, 0
-        self._fused_active = self._fused_eligible()
         self._fused_counts_ready = False
         if self._fused_active:
             self._stats_known = False  # row lengths come from the consumer's plan compile
@@ -331,6 +294,80 @@ class Cell(NeighborList):
         self._built_consumer_version = self._consumer_version
         self._disp, self._disp_generation = 0.0, state.position_generation
         self.num_builds += 1
+
+    # Cells of half the list radius for the fused plan compile (azp_nlist_args.cell_subdivision = 2, csrc/pair_plan_cells.hip):
+    # 0 never, 1 when it pays (a box of >= 8 such cells along every periodic axis, >= 0.75 particles per cell),
+    # 2 whenever the compiler can take them (>= 5 cells along every periodic axis; tests)
+    half_cells = int(os.environ.get("AZP_HALF_CELLS", "1"))
+
+    def _half_cells_wanted(self, box, rl_max, n_total):
+        mode = self.half_cells
+        if mode <= 0 or getattr(self, "_half_failures", 0) >= 2:
+            return False
+        L = box.L
+        dims = [max(int(np.floor(L[k] / (0.5 * rl_max))), 1) for k in range(3)]
+        need = 5 if mode >= 2 else 8
+        if any(box.periodic[k] and dims[k] < need for k in range(3)):
+            return False
+        return mode >= 2 or n_total >= 0.75 * dims[0] * dims[1] * dims[2]
+
+    def _bin(self, a, box, rl_max, n_total, sub, dev, stream):
+        """Bin the particles of ``a.d_pos`` into cells at least ``rl_max / sub`` wide: fills the grid, d_cell_of,
+        d_order, d_cell_start of ``a``; returns the tensors to keep alive."""
+        import torch
+
+        l = _lib.lib()
+        L = box.L
+        for k in range(3):
+            dim = max(int(np.floor(L[k] / (rl_max / sub))), 1)
+            a.grid.dim[k] = dim
+            a.grid.width[k] = L[k] / dim
+            a.grid.lo[k] = -0.5 * L[k]
+            a.grid.periodic[k] = 1 if box.periodic[k] else 0
+        a.cell_subdivision = sub
+        ncell = int(a.grid.dim[0]) * int(a.grid.dim[1]) * int(a.grid.dim[2])
+        cell_of = torch.empty(n_total, dtype=torch.int32, device=dev)
+        a.d_cell_of = cell_of.data_ptr()
+        native = self.native_binning if self.native_binning is not None else (ncell > 65536)
+        if native and n_total <= 128 * ncell:
+            # one libazp call (counting sort, stable in the particle index): five small kernels back to back instead
+            # of a framework sort pipeline of a dozen launches with host gaps between them. Cells that hold very many
+            # particles (tiny boxes) take the general path: the per-cell sort is quadratic in the cell's population.
+            order = torch.empty(n_total, dtype=torch.int32, device=dev)
+            cell_start = torch.empty(ncell + 1, dtype=torch.int32, device=dev)
+            cursor = torch.empty(ncell, dtype=torch.int32, device=dev)
+            order_tmp = torch.empty(n_total, dtype=torch.int32, device=dev)
+            a.d_order = order.data_ptr()
+            a.d_cell_start = cell_start.data_ptr()
+            _lib.check(l.azp_nlist_bin(C.byref(a), cursor.data_ptr(), order_tmp.data_ptr(), stream), "azp_nlist_bin")
+            return (cell_of, order, cell_start, cursor, order_tmp)
+        _lib.check(l.azp_nlist_cell_assign(C.byref(a), stream), "azp_nlist_cell_assign")
+        if ncell <= 65536:
+            # 16-bit keys: two radix passes instead of four (0.06 instead of 0.16 ms at N = 2^20); same permutation
+            k16, order = torch.sort((cell_of - 32768).to(torch.int16), stable=True)
+            cell_sorted = k16.to(torch.int32) + 32768
+        else:
+            cell_sorted, order = torch.sort(cell_of, stable=True)
+        order = order.to(torch.int32)
+        cell_start = torch.empty(ncell + 1, dtype=torch.int32, device=dev)
+        a.d_cell_sorted = cell_sorted.data_ptr()
+        a.d_order = order.data_ptr()
+        a.d_cell_start = cell_start.data_ptr()
+        _lib.check(l.azp_nlist_cell_bounds(C.byref(a), stream), "azp_nlist_cell_bounds")
+        return (cell_of, cell_sorted, order, cell_start)
+
+    def rebin_full(self):
+        """Half-width cells did not work out for this build (a consumer's plan compile refused them, or somebody needs
+        the HOOMD-format list): bin the same positions again into cells of the full list radius."""
+        import torch
+
+        a = self._cells
+        if a.cell_subdivision != 2:
+            return
+        a.d_pos = self._pos_at_build.data_ptr()
+        dev = self._pos_at_build.device
+        bins = self._bin(a, self._box_at_build, self._rl_max, a.n_total, 1, dev, torch.cuda.current_stream(dev).cuda_stream)
+        self._keep = (self._keep[0], bins, self._keep[2])
 
     def _fused_eligible(self):
         if not self.fused or getattr(self, "_compact", False) or len(self._consumers) != 1:
@@ -358,6 +395,7 @@ class Cell(NeighborList):
         if self._nlist is None and self.n_neigh is not None:
             import torch
 
+            self.rebin_full()
             a = self._cells
             a.d_pos = self._pos_at_build.data_ptr()
             self._fill(torch.cuda.current_stream(self._pos_at_build.device).cuda_stream)

@@ -303,12 +303,22 @@ class Pair(Force):
             cap = getattr(nl, "_plan_row_capacity", 0) or 160
             info = None
             self._plan.set_balance(self._plan_balance)
-            for _ in range(3):
+            for _ in range(4):
                 self._plan.build_from_cells(nl.cells_args(cap), a, stream)
                 info = self._plan.info()
-                if info["valid"] or info["invalid_reason"] != 3:
+                if info["valid"]:
+                    if nl._cells.cell_subdivision == 2:
+                        nl._half_failures = 0
                     break
-                cap = (int(info["max_row"] * 1.06) + 4 + 7) // 8 * 8  # a row overflowed: longer rows (HOOMD's protocol)
+                if info["invalid_reason"] == 3:
+                    cap = (int(info["max_row"] * 1.06) + 4 + 7) // 8 * 8  # a row overflowed: longer rows (HOOMD's protocol)
+                elif nl._cells.cell_subdivision == 2:
+                    # half-width cells refused (a tile's members too spread out, a very dense run of cells): bin the
+                    # same positions into cells of the full list radius and compile from those
+                    nl._half_failures = getattr(nl, "_half_failures", 0) + 1
+                    nl.rebin_full()
+                else:
+                    break
             a.range_first, a.range_count = first, count
             self._plan_valid = bool(info["valid"])
             if info["valid"]:

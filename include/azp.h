@@ -385,7 +385,7 @@ int azp_bond_forces_quartic(const azp_bond_args* args, const azp_quartic_params*
 typedef struct azp_cell_grid
     {
     double lo[3];        /* lower corner of the grid                     */
-    double width[3];     /* cell width, >= largest r_list                */
+    double width[3];     /* cell width, >= largest r_list (>= half of it with azp_nlist_args.cell_subdivision = 2) */
     uint32_t dim[3];
     int32_t periodic[3]; /* 1: cell index wraps; 0: clamped (ghost slab) */
     } azp_cell_grid;
@@ -398,7 +398,11 @@ typedef struct azp_nlist_args
     azp_box box;
     azp_cell_grid grid;
     uint32_t ntypes;
-    uint32_t _pad;
+    /* 0 / 1: cells at least as wide as the largest r_list (every entry point). 2: cells at least HALF as wide
+     * (azp_nlist_cell_assign / cell_bounds / bin and azp_pair_plan_build_from_cells only: the plan compiler then
+     * searches the 5 x 5 x 5 cells around a particle's own, cut down per particle to the cells its list sphere
+     * reaches -- 0.39 x the candidate tests; azp_nlist_count / fill refuse such cells) */
+    uint32_t cell_subdivision;
     const double* d_rlistsq;    /* ntypes^2, (r_cut + r_buff)^2; <= 0 disables the pair */
     uint32_t* d_cell_of;        /* n_total, written by cell_assign            */
     const uint32_t* d_cell_sorted; /* n_total, d_cell_of in ascending order   */

@@ -257,10 +257,12 @@ def rel_err(a, b):
 # ---------------------------------------------------------------------------
 # binned particles (azp_nlist_args) for the plan-from-cells compiler
 # ---------------------------------------------------------------------------
-def gpu_cells(pos, box, r_list, ntypes=1, N=None, exclusions=None, row_capacity=0):
-    """Bin ``pos`` (n_total x 4, ghosts after the N locals) into cells of width >= max r_list with
+def gpu_cells(pos, box, r_list, ntypes=1, N=None, exclusions=None, row_capacity=0, sub=1):
+    """Bin ``pos`` (n_total x 4, ghosts after the N locals) into cells of width >= max r_list / sub with
     libazp's own kernels (azp_nlist_cell_assign / _cell_bounds) and return (azp_nlist_args, keepalive).
-    ``box``: (L, tilt, periodic) as for gpu_pair_args; ``exclusions``: (n_excl, excl[N, max])."""
+    ``box``: (L, tilt, periodic) as for gpu_pair_args; ``exclusions``: (n_excl, excl[N, max]). ``sub`` = 2: cells of
+    half the list radius (azp_nlist_args.cell_subdivision) where the plan compiler can take them (>= 5 cells along
+    every periodic axis), else cells of the full radius as the product does."""
     import torch
 
     pos = np.ascontiguousarray(pos, dtype=np.float64)
@@ -275,8 +277,11 @@ def gpu_cells(pos, box, r_list, ntypes=1, N=None, exclusions=None, row_capacity=
     L = tuple(a.box.L)
     periodic = tuple(a.box.periodic)
     ncell = 1
+    if sub == 2 and any(periodic[k] and int(np.floor(L[k] / (0.5 * rl.max()))) < 5 for k in range(3)):
+        sub = 1
+    a.cell_subdivision = sub
     for k in range(3):
-        dim = max(int(np.floor(L[k] / rl.max())), 1)
+        dim = max(int(np.floor(L[k] / (rl.max() / sub))), 1)
         a.grid.dim[k] = dim
         a.grid.width[k] = L[k] / dim
         a.grid.lo[k] = -0.5 * L[k]

@@ -22,6 +22,25 @@ from test_gpu_parity import PAIR_PARAMS, _params_table, assert_close
 
 pytestmark = pytest.mark.gpu
 
+_SUB = 1
+
+
+@pytest.fixture(autouse=True, params=[1, 2], ids=["cells", "halfcells"])
+def cell_subdivision(request):
+    """Every case twice: cells of the full list radius (27 cells around a member cell) and cells of half of it (the
+    5 x 5 x 5 cells around a member's own, cut down per member; azp_nlist_args.cell_subdivision = 2) -- through the C ABI
+    (``fused_forces``) and through the API (``nlist.Cell.half_cells``: 0 never, 2 whenever the compiler takes them)."""
+    global _SUB
+    from azplugins_amd import nlist
+
+    old = nlist.Cell.half_cells
+    _SUB = request.param
+    nlist.Cell.half_cells = 2 if request.param == 2 else 0
+    yield request.param
+    nlist.Cell.half_cells = old
+    _SUB = 1
+
+
 PLJ = "PerturbedLennardJones"
 PLANNED = {
     PLJ: "azp_pair_forces_planned_perturbed_lennard_jones",
@@ -32,7 +51,7 @@ PLANNED = {
 
 
 def fused_forces(name, pos, box, params, r_cut, r_buff, ntypes=1, N=None, mode="none", r_on=0.0, virial=False, exclusions=None,
-                 row_capacity=0, moved=None, bound=None, prange=None, r_inner=None, balance=False, disp=None):
+                 row_capacity=0, moved=None, bound=None, prange=None, r_inner=None, balance=False, disp=None, sub=0):
     """Bin, compile the plan from the bins, run the planned kernel; returns (force[, virial], info)."""
     import torch
 
@@ -40,7 +59,7 @@ def fused_forces(name, pos, box, params, r_cut, r_buff, ntypes=1, N=None, mode="
 
     rc = np.broadcast_to(np.asarray(r_cut, dtype=np.float64), (ntypes, ntypes))
     rl = np.where(rc > 0, rc + r_buff, 0.0)
-    cells, keep = H.gpu_cells(pos, box, rl, ntypes, N, exclusions, row_capacity)
+    cells, keep = H.gpu_cells(pos, box, rl, ntypes, N, exclusions, row_capacity, sub=sub if sub else _SUB)
     n_total = pos.shape[0]
     N = n_total if N is None else N
     dummy = (np.zeros(N, np.uint32), np.zeros(N, np.uint64), np.zeros(1, np.uint32))
@@ -53,6 +72,12 @@ def fused_forces(name, pos, box, params, r_cut, r_buff, ntypes=1, N=None, mode="
     plan.set_balance(balance)
     plan.build_from_cells(cells, a, H._stream())
     info = plan.info()
+    info["cell_subdivision"] = int(cells.cell_subdivision)
+    if not info["valid"] and cells.cell_subdivision == 2 and info["invalid_reason"] in (4, 5):
+        # half-width cells refused (the local grid of some tile has more than 2,048 cells): cells of the full radius, as
+        # azplugins_amd.pair does
+        return fused_forces(name, pos, box, params, r_cut, r_buff, ntypes, N, mode, r_on, virial, exclusions, row_capacity, moved,
+                            bound, prange, r_inner, balance, disp, sub=1)
     if not info["valid"]:
         return None, info
     a.d_nlist, a.d_head_list, a.size_nlist = info["list_id"], info["head_id"], 0

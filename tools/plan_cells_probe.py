@@ -31,18 +31,17 @@ pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=cfg["r_cut"])
 pot.params[("A", "A")] = cfg["params"]
 sim.operations.integrator = azp.Integrator(dt=0.005, forces=[pot], methods=[azp.ConstantVolume()])
 sim.operations.tuners.clear()
-stop = int(os.environ.get("AZP_PLAN_CELLS_STOP", "0"))
+stop = int(os.environ.pop("AZP_PLAN_CELLS_STOP", "0"))   # (handed to the library only for the timed builds)
 if args.melt:
-    assert not stop
     sim.run(0)
     sim.thermalize_particle_momenta(1.0, seed=7)
     sim.run(args.melt)
     azp.ParticleSorter().sort(sim)
-nl.fused = not stop          # a stopped kernel leaves no plan: keep the force path on the list
 sim.run(0)
-nl.fused = True
 nl._build(sim.state)         # bins only (fused mode fills no list)
-a = pot._pair_args()
+if stop:
+    os.environ["AZP_PLAN_CELLS_STOP"] = str(stop)
+a = pot._pair_args(for_launch=True)   # (keeps the list fused: no HOOMD-format rows, the bins stay as they are)
 stream = torch.cuda.current_stream().cuda_stream
 plan = azp._lib.PairPlan()
 cells = nl.cells_args(160)
@@ -54,4 +53,4 @@ for _ in range(args.reps):
     plan.build_from_cells(cells, a, stream)
 e1.record()
 torch.cuda.synchronize()
-print("stop_after=%d  build_from_cells %.3f ms  info %s" % (stop, e0.elapsed_time(e1) / args.reps, plan.info()))
+print("stop_after=%d  cell_subdivision=%d  build_from_cells %.3f ms  info %s" % (stop, cells.cell_subdivision, e0.elapsed_time(e1) / args.reps, plan.info()))
