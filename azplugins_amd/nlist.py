@@ -283,7 +283,9 @@ class Cell(NeighborList):
         self.n_neigh = n_neigh
         self._cells = a
         self._keep = (rlistsq, bins, keep)
-        self._pos_at_build = state.pos[:n_total].clone()
+        # (an elementwise kernel, not clone(): the runtime's device-to-device copy of these 32 MB takes 150 us at N = 2^20,
+        # 0.016 ms per MD step at one rebuild per 9 steps; x * 1.0 is exact and runs at memory speed)
+        self._pos_at_build = state.pos[:n_total] * 1.0
         self._nlist, self._head_list, self._size = None, None, 0
         self._fused_counts_ready = False
         if self._fused_active:
@@ -296,9 +298,13 @@ class Cell(NeighborList):
         self.num_builds += 1
 
     # Cells of half the list radius for the fused plan compile (azp_nlist_args.cell_subdivision = 2, csrc/pair_plan_cells.hip):
-    # 0 never, 1 when it pays (a box of >= 8 such cells along every periodic axis, >= 0.75 particles per cell),
-    # 2 whenever the compiler can take them (>= 5 cells along every periodic axis; tests)
-    half_cells = int(os.environ.get("AZP_HALF_CELLS", "1"))
+    # 0 never (default), 1 when the geometry suits them (a box of >= 8 such cells along every periodic axis, >= 0.75
+    # particles per cell), 2 whenever the compiler can take them (>= 5 cells along every periodic axis; tests).
+    # Measured on the north-star liquid: 338 instead of 864 candidate tests per particle, but the same
+    # 1.7 ms per build -- with every lane on its own candidates the waves lose the lock-step of the full-width form (all
+    # members of a cell walk the same candidates, and a pair of candidates nobody in the wave accepts skips the accept
+    # path), and the finer binning costs more. Kept as an exact, tested alternative; off by default.
+    half_cells = int(os.environ.get("AZP_HALF_CELLS", "0"))
 
     def _half_cells_wanted(self, box, rl_max, n_total):
         mode = self.half_cells
