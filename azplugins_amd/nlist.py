@@ -283,9 +283,7 @@ class Cell(NeighborList):
         self.n_neigh = n_neigh
         self._cells = a
         self._keep = (rlistsq, bins, keep)
-        # (an elementwise kernel, not clone(): the runtime's device-to-device copy of these 32 MB takes 150 us at N = 2^20,
-        # 0.016 ms per MD step at one rebuild per 9 steps; x * 1.0 is exact and runs at memory speed)
-        self._pos_at_build = state.pos[:n_total] * 1.0
+        self._pos_at_build = state.pos[:n_total].clone()
         self._nlist, self._head_list, self._size = None, None, 0
         self._fused_counts_ready = False
         if self._fused_active:
