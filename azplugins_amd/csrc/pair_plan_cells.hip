@@ -815,21 +815,22 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
             // single-precision math: one instruction per pair of differences / products)
             typedef float f2 __attribute__((ext_vector_type(2)));
             const f2 xi2 = {xi, xi}, yi2 = {yi, yi}, zi2 = {zi, zi};
-            // (the runs ascend: one that starts behind the batch ends the walk, and the next batch resumes at the
-            // first run this one did not use up -- without that every lane trudges through its remaining runs at
-            // the end of every batch, each on its own trip of the wave)
+            // (half-width cells -- the runs ascend: one that starts behind the batch ends the walk, and the next batch
+            // resumes at the first run this one did not use up; without that every lane trudges through its remaining
+            // runs at the end of every batch, each on its own trip of the wave. Full-width cells: the members of a cell
+            // move in lock-step and the plain walk is cheaper)
             uint32_t q = qres, g = 0, l1 = 0;
             const uint32_t bend = b0 + nbat;
             while (g >= l1 && q < n_runs)
                 {
                 uint32_t rf, re;
                 fetch_run(q, rf, re);
-                if (rf >= bend)
+                if (HALF && rf >= bend)
                     {
                     q = n_runs;
                     break;
                     }
-                qres = (re <= bend && qres == q) ? q + 1u : qres; // (an empty run behind one that reaches into the next batch must not step over it)
+                qres = (HALF && re <= bend && qres == q) ? q + 1u : qres; // (an empty run behind one that reaches into the next batch must not step over it)
                 ++q;
                 g = max(rf, b0);
                 l1 = min(re, bend);
@@ -859,12 +860,12 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
                     {
                     uint32_t rf, re;
                     fetch_run(q, rf, re);
-                    if (rf >= bend)
+                    if (HALF && rf >= bend)
                         {
                         q = n_runs;
                         break;
                         }
-                    qres = (re <= bend && qres == q) ? q + 1u : qres; // (an empty run behind one that reaches into the next batch must not step over it)
+                    qres = (HALF && re <= bend && qres == q) ? q + 1u : qres; // (an empty run behind one that reaches into the next batch must not step over it)
                     ++q;
                     g = max(rf, b0);
                     l1 = min(re, bend);
