@@ -276,8 +276,6 @@ def rank_simulation(cfg, decomp, rank, device, seed=1):
     """Simulation of one rank of a decomposed run: its local particles from a replicated
     synthetic configuration (every rank regenerates it from the hash RNG), a DeviceDomain
     that has selected its ghosts, and the State pointed at the domain's arrays."""
-    from .domain import DeviceDomain
-    from .simulation import Simulation
     from .state import Snapshot
 
     xyz = cfg["xyz"]
@@ -289,21 +287,102 @@ def rank_simulation(cfg, decomp, rank, device, seed=1):
         snap.particles.moment_inertia[:] = cfg["inertia"][mine]
     if "angmom" in cfg:
         snap.particles.angmom[:] = cfg["angmom"][mine]
-    sim = Simulation(device=device, seed=seed)
-    st = sim.create_state_from_snapshot(snap)
-    arrays = dict(pos=st.pos, vel=st.vel, orientation=st.orientation, tag=st.tag, image=st.image, angmom=st.angmom, inertia=st.inertia)
-    dom = DeviceDomain(decomp, rank, arrays, density=xyz.shape[0] / float(np.prod(decomp.L)))
-    dom.rebuild()
+    topology = None
     if cfg.get("bonds") is not None and len(cfg["bonds"]):
         # the topology by tag, replicated (tags = indices of the global configuration unless cfg carries its own)
         gtag = np.asarray(cfg["tag"], dtype=np.int64) if "tag" in cfg else np.arange(xyz.shape[0], dtype=np.int64)
         b = np.asarray(cfg["bonds"], dtype=np.int64).reshape(-1, 2)
+        topology = dict(bond_tags=gtag[b], bond_typeid=cfg.get("bond_typeid", np.zeros(b.shape[0], dtype=np.uint32)),
+                        bond_types=cfg.get("bond_types", ("A-A",)))
+    return rank_simulation_from_snapshot(snap, xyz.shape[0], decomp, rank, device, seed=seed, topology=topology)
+
+
+def rank_simulation_from_snapshot(snap, n_global, decomp, rank, device, seed=1, topology=None):
+    """Simulation of one rank from the snapshot of ITS particles (``distribute_snapshot`` hands every rank its share of
+    a snapshot that only the root holds): DeviceDomain with ghosts selected, State pointed at the domain's arrays,
+    bonds (``topology``: the global bond list by tag, ``distribute_snapshot``'s second result) localized."""
+    from .domain import DeviceDomain
+    from .simulation import Simulation
+
+    sim = Simulation(device=device, seed=seed)
+    st = sim.create_state_from_snapshot(snap)
+    arrays = dict(pos=st.pos, vel=st.vel, orientation=st.orientation, tag=st.tag, image=st.image, angmom=st.angmom, inertia=st.inertia)
+    dom = DeviceDomain(decomp, rank, arrays, density=n_global / float(np.prod(decomp.L)))
+    dom.rebuild()
+    if topology is not None and len(topology["bond_tags"]):
         st.N, st.n_ghost = dom.N_local, dom.n_ghost
         for n in dom.names:
             setattr(st, n, dom.arrays[n])
-        st.set_global_bonds(gtag[b], cfg.get("bond_typeid", np.zeros(b.shape[0], dtype=np.uint32)), cfg.get("bond_types", ("A-A",)))
+        st.set_global_bonds(np.asarray(topology["bond_tags"], dtype=np.int64), topology["bond_typeid"], topology["bond_types"])
     sim.attach_domain(dom)
     return sim, dom
+
+
+# one row per particle on the wire (float64: tags and type ids are exact): position, type id, orientation, velocity,
+# mass, moments of inertia, angular momentum, tag
+_WIRE = (("position", 3), ("typeid", 1), ("orientation", 4), ("velocity", 3), ("mass", 1), ("moment_inertia", 3), ("angmom", 4), ("tag", 1))
+
+
+def distribute_snapshot(snap, decomp, root=0, device=None, group=None):
+    """HOOMD's ``create_state_from_snapshot`` under MPI: only ``root`` holds the snapshot (the others pass ``None``),
+    every rank gets the particles its sub-box owns. Collective: the small things (box, type names, the bond topology by
+    tag, the per-rank counts) are broadcast, the particle rows travel in ONE ``all_to_all_single`` in which only the root
+    sends (RCCL; gloo on CPU tensors in the tests). Returns ``(local_snapshot, n_global, topology)`` for
+    ``rank_simulation_from_snapshot``; ``topology`` is None without bonds."""
+    import torch
+    import torch.distributed as dist
+
+    from .state import Snapshot
+
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        topo = None
+        if snap.bonds.N:
+            topo = dict(bond_tags=snap.particles.tag.astype(np.int64)[snap.bonds.group.astype(np.int64)], bond_typeid=snap.bonds.typeid.copy(),
+                        bond_types=tuple(snap.bonds.types))
+        return snap, snap.particles.N, topo
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    width = sum(w for _, w in _WIRE)
+    meta = [None]
+    rows = None
+    if rank == root:
+        p = snap.particles
+        rows = np.empty((p.N, width))
+        c = 0
+        for name, w in _WIRE:
+            rows[:, c:c + w] = np.asarray(getattr(p, name), dtype=np.float64).reshape(p.N, w)
+            c += w
+        owner = decomp.owner(p.position)
+        order = np.argsort(owner, kind="stable")
+        rows = np.ascontiguousarray(rows[order])
+        box = snap.configuration.box
+        meta = [dict(counts=np.bincount(owner, minlength=world).tolist(), n_global=int(p.N), types=list(p.types), L=list(box.L),
+                     tilt=[box.xy, box.xz, box.yz], periodic=list(box.periodic),
+                     bond_tags=p.tag.astype(np.int64)[snap.bonds.group.astype(np.int64)] if snap.bonds.N else None,
+                     bond_typeid=snap.bonds.typeid.copy() if snap.bonds.N else None, bond_types=tuple(snap.bonds.types))]
+    dist.broadcast_object_list(meta, src=root, group=group)
+    m = meta[0]
+    dev = "cpu" if dist.get_backend(group) == "gloo" else device
+    n_me = int(m["counts"][rank])
+    send = torch.from_numpy(rows).to(dev) if rank == root else torch.empty((0, width), dtype=torch.float64, device=dev)
+    recv = torch.empty((n_me, width), dtype=torch.float64, device=dev)
+    dist.all_to_all_single(recv, send, output_split_sizes=[n_me if r == root else 0 for r in range(world)],
+                           input_split_sizes=[int(c) for c in m["counts"]] if rank == root else [0] * world, group=group)
+    r = recv.cpu().numpy()
+    local = Snapshot()
+    local.particles.N = n_me
+    local.particles.types = list(m["types"])
+    c = 0
+    for name, w in _WIRE:
+        dst = getattr(local.particles, name)
+        dst[...] = r[:, c:c + w].reshape(dst.shape).astype(dst.dtype)
+        c += w
+    from .state import Box
+
+    local.configuration.box = Box(m["L"][0], m["L"][1], m["L"][2], *m["tilt"], periodic=tuple(m["periodic"]))
+    topo = None
+    if m["bond_tags"] is not None:
+        topo = dict(bond_tags=m["bond_tags"], bond_typeid=m["bond_typeid"], bond_types=m["bond_types"])
+    return local, m["n_global"], topo
 
 
 def bench_main(args, rank, world, local_rank):

@@ -183,3 +183,62 @@ def test_migration_ghosts_and_packed_exchange_gloo(kind, world, tmp_path, oracle
             seen[d["tag%d" % step]] += 1
         assert np.all(seen == 1), "step %d: every particle has exactly one owner" % step
         assert np.abs(f - f_ref).max() <= 1e-11 * np.abs(f_ref).max(), "step %d" % step
+
+
+def _global_snapshot():
+    """A system with every per-particle field set to something of its own, tags that are not the indices, two types and bonds."""
+    from azplugins_amd.state import Snapshot
+
+    cfg = syn.config_chains(8, 8, 8, 8)
+    n = cfg["xyz"].shape[0]
+    idx = np.arange(n, dtype=np.uint64)
+    tag = ((idx * 7919) % n).astype(np.uint32)   # a permutation: 7919 is prime and does not divide n
+    assert np.unique(tag).size == n
+    snap = Snapshot.from_arrays(cfg["xyz"], cfg["L"], typeid=(idx % 2).astype(np.uint32), types=("A", "B"), tag=tag,
+                                velocity=np.stack([syn.normal(3, idx, c) for c in range(3)], axis=1),
+                                orientation=syn.random_quaternions(n, 5),
+                                bonds=cfg["bonds"], moment_inertia=np.stack([0.1 + syn.u01(4, idx, c) for c in range(3)], axis=1),
+                                angmom=np.stack([syn.normal(6, idx, c) for c in range(4)], axis=1))
+    snap.particles.mass[:] = 1.0 + syn.u01(8, idx, 0)
+    return snap, cfg
+
+
+def _distribute_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    snap, cfg = _global_snapshot() if rank == 0 else (None, syn.config_chains(8, 8, 8, 8))
+    dec = dd.Decomposition(cfg["L"], world, 2.9)
+    local, n_global, topo = dd.distribute_snapshot(snap, dec, root=0)
+    p = local.particles
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), n_global=np.array([n_global]), position=p.position, typeid=p.typeid, orientation=p.orientation,
+             velocity=p.velocity, mass=p.mass, moment_inertia=p.moment_inertia, angmom=p.angmom, tag=p.tag, types=np.array(p.types),
+             L=local.configuration.box.L, bond_tags=topo["bond_tags"], bond_typeid=topo["bond_typeid"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_distribute_snapshot_gloo(world, tmp_path):
+    """Only rank 0 holds the snapshot: every rank receives exactly the particles its sub-box owns, field by field, in the
+    snapshot's order, and the bond topology by tag (HOOMD: create_state_from_snapshot under MPI)."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_distribute_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    snap, cfg = _global_snapshot()
+    g = snap.particles
+    dec = dd.Decomposition(cfg["L"], world, 2.9)
+    owner = dec.owner(g.position)
+    seen = 0
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        mine = np.flatnonzero(owner == r)
+        assert int(d["n_global"][0]) == g.N and list(d["types"]) == ["A", "B"] and np.array_equal(d["L"], np.asarray(cfg["L"], dtype=np.float64))
+        for name in ("position", "typeid", "orientation", "velocity", "mass", "moment_inertia", "angmom", "tag"):
+            assert np.array_equal(d[name], getattr(g, name)[mine]), (r, name)
+        assert np.array_equal(d["bond_tags"], g.tag.astype(np.int64)[snap.bonds.group.astype(np.int64)])
+        assert np.array_equal(d["bond_typeid"], snap.bonds.typeid)
+        seen += mine.size
+    assert seen == g.N

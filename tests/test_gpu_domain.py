@@ -7,7 +7,8 @@ initial state ends (positions and velocities by tag). Covers the PerturbedLJ til
 with its displacement bound on moving ghosts, the DPD thermostat (both owners of a
 cross-rank pair must draw the same random number), TwoPatchMorse with rotational degrees of freedom
 (orientations, angular momenta and moments of inertia migrate) and a bonded system (PerturbedLJ +
-DoubleWell: two forces on one list, the bond table rebuilt from the topology by tag after every migration)."""
+DoubleWell: two forces on one list, the bond table rebuilt from the topology by tag after every migration). The last
+two start from a snapshot that only rank 0 holds (decomposition.distribute_snapshot)."""
 
 import os
 import socket
@@ -85,6 +86,14 @@ def _integrator(azp, kind, cfg, nl):
     return pot, azp.Integrator(dt=cfg["dt"], forces=forces, methods=[azp.ConstantVolume()], integrate_rotational_dof=(kind == "tpm"))
 
 
+def _snapshot(azp, kind, cfg):
+    snap = azp.Snapshot.from_arrays(cfg["xyz"], cfg["L"], tag=cfg.get("tag"), velocity=cfg["vel"], orientation=cfg.get("orientation"),
+                                    bonds=cfg.get("bonds") if kind == "chains" else None)
+    if "inertia" in cfg:
+        snap.particles.moment_inertia[:] = cfg["inertia"]
+    return snap
+
+
 def _worker(rank, world, port, out_dir, kind):
     import torch
     import torch.distributed as dist
@@ -98,7 +107,13 @@ def _worker(rank, world, port, out_dir, kind):
     torch.cuda.set_device(0)
     cfg = _config(kind)
     dec = dd.Decomposition(cfg["L"], world, cfg["r_cut"] + cfg["r_buff"])
-    sim, dom = dd.rank_simulation(cfg, dec, rank, "cuda:0", seed=cfg.get("seed", 1))
+    if kind in ("tpm", "chains"):
+        # only rank 0 holds the snapshot (HOOMD's create_state_from_snapshot under MPI): every rank receives its share
+        snap = _snapshot(azp, kind, cfg) if rank == 0 else None
+        local, n_global, topology = dd.distribute_snapshot(snap, dec, root=0, device="cuda:0")
+        sim, dom = dd.rank_simulation_from_snapshot(local, n_global, dec, rank, "cuda:0", seed=cfg.get("seed", 1), topology=topology)
+    else:
+        sim, dom = dd.rank_simulation(cfg, dec, rank, "cuda:0", seed=cfg.get("seed", 1))
     nl = azp.nlist.Cell(buffer=cfg["r_buff"])
     pot, sim.operations.integrator = _integrator(azp, kind, cfg, nl)
     sim.run(cfg["steps"])
@@ -125,11 +140,7 @@ def test_decomposed_md_run_matches_single_domain(kind, tmp_path):
     cfg = _config(kind)
     n = cfg["xyz"].shape[0]
     sim = azp.Simulation(device="cuda:0", seed=cfg.get("seed", 1))
-    snap = azp.Snapshot.from_arrays(cfg["xyz"], cfg["L"], tag=cfg.get("tag"), velocity=cfg["vel"], orientation=cfg.get("orientation"),
-                                    bonds=cfg.get("bonds") if kind == "chains" else None)
-    if "inertia" in cfg:
-        snap.particles.moment_inertia[:] = cfg["inertia"]
-    sim.create_state_from_snapshot(snap)
+    sim.create_state_from_snapshot(_snapshot(azp, kind, cfg))
     nl = azp.nlist.Cell(buffer=cfg["r_buff"])
     pot, sim.operations.integrator = _integrator(azp, kind, cfg, nl)
     sim.operations.tuners.clear()
