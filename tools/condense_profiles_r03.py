@@ -84,8 +84,9 @@ wr, nw = counters("bench_write", "pair_forces_tiled_kernel<azp::EvalPLJ")
 if fe and wr:
     d = {"_comment": "HBM traffic per launch of the tile kernel, mean over the launches of `python3 bench.py --no-cpu-baseline --no-side-figures %s` (recorded "
                      "cycle + run-in + warm-up + timed + verification launches), separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes. Units KiB; on gfx950 "
-                     "FETCH_SIZE reports half the bytes of wide coalesced streams (MI355X_MICROARCH.md, HBM section), hence fetch_correction = 2. WRITE_SIZE "
-                     "exceeds the 32 MiB force array by the kernel's register-spill traffic (the accumulators of the core path, spilled around the tail path)." % DRV,
+                     "FETCH_SIZE reports half the bytes of wide coalesced streams (MI355X_MICROARCH.md, HBM section), hence fetch_correction = 2. The force array is 32 MiB "
+                     "(32,768 KiB): WRITE_SIZE above that is register-spill traffic that reached HBM (the kernel keeps 116-224 B of scratch per lane around its tail path; "
+                     "41.5 MiB in an earlier pass of the round, none in this one: every full launch wrote exactly 32,768 KiB, the mean includes the early exits)." % DRV,
          K: dict(workload="NS", FETCH_SIZE_KiB=fe["FETCH_SIZE"], WRITE_SIZE_KiB=wr["WRITE_SIZE"], fetch_correction=2.0, launches=nf,
                  note="mean over an MD rebuild cycle at the sustained clock; final binary of round 3")}
     json.dump(d, open(os.path.join(P, "r03_traffic.json"), "w"), indent=1)
