@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
     // Half-width cells: the per-thread run tables and the prefix of the local grid's cell populations sit behind the
     // batch; counters, bitmap and slot table take the place of batch and run tables once the tests are done.
     constexpr uint32_t BATCH = HALF ? PC_BATCH_H : PC_BATCH;
-    constexpr uint32_t CSTRIDE = BATCH + 2;                  // one pad entry: candidates are read two at a time
+    constexpr uint32_t CSTRIDE = BATCH + 4;                  // pad entries: candidates are read two / four at a time
     constexpr uint32_t CAND_BYTES = (CSTRIDE * 16 + BATCH + 32 + 15) / 16 * 16; // x | y | z | particle index | types
     constexpr uint32_t CUR_BYTES = PLAN_CLASSES * PC_THREADS * 2;
     constexpr uint32_t RUNG_OFF = CAND_BYTES;                                  // HALF: u16 [run][thread], first candidate
@@ -835,40 +835,20 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
                 g = max(rf, b0);
                 l1 = min(re, bend);
                 }
-            while (g < l1)
+            // two candidates (c0, c0 + 1; numbers g0, g0 + 1; the first valid if va, the second if vb) against my member
+            auto judge2 = [&](uint32_t g0, uint32_t c0, bool va, bool vb, f2 X, f2 Y, f2 Z)
                 {
-                const uint32_t gc = g, c = g - b0;
-                const bool second = gc + 1u < l1; // (else the pad entry / the next cell's first candidate: ignored)
-#ifdef AZP_PLAN_CELLS_PROFILE
-                ++prof_trips;
-                prof_tests += second ? 2u : 1u;
-#endif
-                const f2 X = {cx[c], cx[c + 1u]}, Y = {cy[c], cy[c + 1u]}, Z = {cz[c], cz[c + 1u]};
                 uint32_t tpa = 0, tpb = 0;
                 float rla = rl1, rlb = rl1;
                 if (!SINGLE)
                     {
-                    tpa = trow + ctype[c];
-                    tpb = trow + (second ? (uint32_t)ctype[c + 1u] : 0u); // (the pad entry holds no type: its byte must not index a table)
+                    // (a pad entry holds no type: its byte must not index a table)
+                    tpa = trow + (va ? (uint32_t)ctype[c0] : 0u);
+                    tpb = trow + (vb ? (uint32_t)ctype[c0 + 1u] : 0u);
                     rla = rc_cached ? s_rlistsq[tpa] : (a.rlistsq[tpa] > 0.0 ? (float)a.rlistsq[tpa] * 1.00001f : -1.f);
                     rlb = rc_cached ? s_rlistsq[tpb] : (a.rlistsq[tpb] > 0.0 ? (float)a.rlistsq[tpb] * 1.00001f : -1.f);
                     rla = rla > 0.f ? rla + rl_extra : rla;
                     rlb = rlb > 0.f ? rlb + rl_extra : rlb;
-                    }
-                g += 2u;
-                while (g >= l1 && q < n_runs)
-                    {
-                    uint32_t rf, re;
-                    fetch_run(q, rf, re);
-                    if (HALF && rf >= bend)
-                        {
-                        q = n_runs;
-                        break;
-                        }
-                    qres = (HALF && re <= bend && qres == q) ? q + 1u : qres; // (an empty run behind one that reaches into the next batch must not step over it)
-                    ++q;
-                    g = max(rf, b0);
-                    l1 = min(re, bend);
                     }
                 f2 dx = xi2 - X, dy = yi2 - Y, dz = zi2 - Z;
                 if (wide)
@@ -880,10 +860,10 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
                     dx = dx - kx * bLx;
                     }
                 const f2 rsq = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-                bool acca = rsq.x <= rla, accb = second && rsq.y <= rlb; // rl < 0: the type pair is not listed
+                bool acca = va && rsq.x <= rla, accb = vb && rsq.y <= rlb; // rl < 0: the type pair is not listed
                 if (acca || accb)
                     {
-                    const uint32_t ja = cj[c], jb = cj[c + 1u];
+                    const uint32_t ja = cj[c0], jb = cj[c0 + 1u];
                     acca = acca && ja != i;
                     accb = accb && jb != i;
                     if (nex)
@@ -916,16 +896,56 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
                     if (acca)
                         {
                         if (cnt < a.row_cap PC_PROFILE_AND(!(a.stop_after & 0x100u)))
-                            raw_tile[cnt * 256u + tid] = (uint16_t)((gc << cbits) | clsa);
+                            raw_tile[cnt * 256u + tid] = (uint16_t)((g0 << cbits) | clsa);
                         ++cnt;
                         }
                     if (accb)
                         {
                         if (cnt < a.row_cap PC_PROFILE_AND(!(a.stop_after & 0x100u)))
-                            raw_tile[cnt * 256u + tid] = (uint16_t)(((gc + 1u) << cbits) | clsb);
+                            raw_tile[cnt * 256u + tid] = (uint16_t)(((g0 + 1u) << cbits) | clsb);
                         ++cnt;
                         }
                     }
+                };
+            // full-width cells: four candidates per trip (the members of a cell walk long runs in lock-step: the loop
+            // control, the run switch and the address arithmetic are paid once per four); half-width cells: two (runs
+            // of a dozen candidates, every lane on its own)
+            constexpr uint32_t PER_TRIP = HALF ? 2u : 4u;
+            while (g < l1)
+                {
+                const uint32_t gc = g, c = g - b0;
+                // (candidates beyond the run's end -- the pad entries / the next cell's first candidates -- are read and ignored)
+                const bool v1 = gc + 1u < l1, v2 = PER_TRIP == 4u && gc + 2u < l1, v3 = PER_TRIP == 4u && gc + 3u < l1;
+#ifdef AZP_PLAN_CELLS_PROFILE
+                ++prof_trips;
+                prof_tests += 1u + (v1 ? 1u : 0u) + (v2 ? 1u : 0u) + (v3 ? 1u : 0u);
+#endif
+                const f2 Xa = {cx[c], cx[c + 1u]}, Ya = {cy[c], cy[c + 1u]}, Za = {cz[c], cz[c + 1u]};
+                f2 Xb = Xa, Yb = Ya, Zb = Za;
+                if (PER_TRIP == 4u)
+                    {
+                    Xb = f2 {cx[c + 2u], cx[c + 3u]};
+                    Yb = f2 {cy[c + 2u], cy[c + 3u]};
+                    Zb = f2 {cz[c + 2u], cz[c + 3u]};
+                    }
+                g += PER_TRIP;
+                while (g >= l1 && q < n_runs)
+                    {
+                    uint32_t rf, re;
+                    fetch_run(q, rf, re);
+                    if (HALF && rf >= bend)
+                        {
+                        q = n_runs;
+                        break;
+                        }
+                    qres = (HALF && re <= bend && qres == q) ? q + 1u : qres; // (an empty run behind one that reaches into the next batch must not step over it)
+                    ++q;
+                    g = max(rf, b0);
+                    l1 = min(re, bend);
+                    }
+                judge2(gc, c, true, v1, Xa, Ya, Za);
+                if (PER_TRIP == 4u)
+                    judge2(gc + 2u, c + 2u, v2, v3, Xb, Yb, Zb);
                 }
             }
         }
