@@ -431,7 +431,9 @@ int azp_nlist_cell_bounds(const azp_nlist_args* args, void* stream);
 /* The binning in one call: d_cell_of, d_order (the particles cell by cell, ascending index inside a cell: what a
  * stable sort by cell gives) and d_cell_start are written (d_cell_sorted is not used). A counting sort: histogram,
  * scan, scatter, and a per-cell sort that makes the result independent of the order of the atomics. Scratch:
- * d_cursor (ncell words), d_order_tmp (n_total words). */
+ * d_cursor (ncell words), d_order_tmp (n_total words; also holds the per-workgroup totals of the scan when the
+ * grid has more than 32,768 cells). Grids of many small cells (cell_subdivision = 2) get a multi-workgroup scan
+ * and a thread-per-cell sort. */
 int azp_nlist_bin(const azp_nlist_args* args, uint32_t* d_cursor, uint32_t* d_order_tmp, void* stream);
 int azp_nlist_count(const azp_nlist_args* args, void* stream);
 int azp_nlist_fill(const azp_nlist_args* args, void* stream);
