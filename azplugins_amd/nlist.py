@@ -188,7 +188,10 @@ class Cell(NeighborList):
                                                       C.byref(box), (0.5 * self.buffer) ** 2, row.data_ptr(),
                                                       row.data_ptr() + 8, self._disp_arr.data_ptr(), stream),
                    "azp_nlist_displacements")
-        done = torch.cuda.Event()
+        ring = self.__dict__.get("_done_events")
+        if ring is None:
+            ring = self._done_events = [torch.cuda.Event() for _ in range(4)]  # (recorded and waited for within one step)
+        done = ring[self._flag_i & 3]
         done.record()
         with torch.cuda.stream(self._side):
             self._side.wait_event(done)
