@@ -881,6 +881,44 @@ def test_api_r_cut_and_mode_change_rebuild_list_and_plan(oracle):
     assert nl.num_builds >= builds + 3  # every r_cut change rebuilt the list
 
 
+def test_api_parameter_change_between_steps_of_a_run(oracle):
+    """The per-step path queues the force kernel behind the list's distance check with the argument struct of the
+    previous step (pair.py, _compute_speculative): new parameters, a new mode or a virial request between two steps must
+    reach the very next launch, not the one after the next list rebuild."""
+    import azplugins_amd as azp
+
+    pos, L, _ = H.lattice_config(12, 1.1, 0.11, seed=34, ntypes=1)
+    p = dict(PAIR_PARAMS["PerturbedLennardJones"](0, 0))
+    sim = azp.Simulation(device="cuda:0", seed=1)
+    sim.create_state_from_snapshot(azp.Snapshot.from_arrays(pos[:, :3], L))
+    nl = azp.nlist.Cell(buffer=0.4)
+    pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=2.5, mode="none")
+    pot.params[("A", "A")] = p
+    sim.operations.integrator = azp.Integrator(dt=0.0005, forces=[pot], methods=[azp.ConstantVolume()])
+    sim.operations.tuners.clear()
+    sim.run(3)
+    box = oracle.make_box(L)
+    builds = nl.num_builds
+    for change in ("epsilon", "mode", "virial", "lambda"):
+        if change == "epsilon":
+            p["epsilon"] = 1.7 * p["epsilon"]
+        elif change == "lambda":
+            p["attraction_scale_factor"] = 0.35
+        if change in ("epsilon", "lambda"):
+            pot.params[("A", "A")] = p
+        if change == "mode":
+            pot.mode = "shift"
+        if change == "virial":
+            pot.compute_virial = True
+        sim.run(2)
+        x = syn.pos4(sim.state.pos[:, :3].cpu().numpy())
+        onl = oracle.build_nlist(x, box, 2.9, half=True)
+        f_ref = oracle.pair_forces("PerturbedLennardJones", x, box, onl, oracle.pack_pair_params("PerturbedLennardJones", p), 2.5,
+                                   mode=pot.mode, half=True)
+        assert_close(np.c_[pot.forces, pot.energies], f_ref, what="after changing %s" % change)
+    assert nl.num_builds == builds  # (nothing here asked for a new list: the launches above took the per-step path)
+
+
 @pytest.mark.parametrize("T", [1, 2])
 def test_planned_dpd_parity(oracle, T):
     """Tile-staged DPD thermostat kernel (azp_dpd_forces_planned_general_weight: positions,
