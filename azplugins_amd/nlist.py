@@ -274,7 +274,7 @@ class Cell(NeighborList):
         bins = self._bin(a, box, rl_max, n_total, sub, dev, stream)
 
         keep = []
-        if "bond" in self.exclusions and state.bond_group.shape[0]:
+        if "bond" in self.exclusions and state.n_bonds:
             n_excl, excl, pitch = state.exclusion_table()
             a.d_n_excl = n_excl.data_ptr()
             a.d_excl = excl.data_ptr()

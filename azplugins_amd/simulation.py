@@ -74,7 +74,7 @@ class Simulation:
         any rank's distance check asks for a neighbor-list rebuild, all ranks migrate their
         particles and re-select their ghosts first (HOOMD: Communicator::migrateParticles /
         exchangeGhosts ahead of NeighborList::compute)."""
-        if self.state.bond_group.shape[0] and self.state.bond_tags is None:
+        if self.state.n_bonds and self.state.bond_tags is None:
             raise _lib.AzpError("attach_domain: a bonded system needs its topology by tag (State.set_global_bonds) -- the "
                                 "index-based bond table of a single-domain state does not survive a migration")
         # every per-particle array that the integrator or a force touches must migrate with the particles

@@ -60,12 +60,11 @@ class ParticleSorter:
         for name in ("pos", "vel", "orientation", "tag", "image", "angmom", "inertia"):
             a = getattr(st, name)
             a[:N] = a[:N].index_select(0, order)
-        if st.bond_group.shape[0]:
+        if st.n_bonds:
             inv = torch.empty(N, dtype=torch.int64, device=st.device)
             inv[order] = torch.arange(N, dtype=torch.int64, device=st.device)
-            # (the 10^6-entry lookup on the device: numpy took 40 ms for C3's bonds)
-            g = torch.from_numpy(st.bond_group.astype(np.int64)).to(st.device)
-            st.bond_group = inv[g].to(torch.int32).cpu().numpy().view(np.uint32).reshape(-1, 2)
+            # (the 10^6-entry lookup on the device, and the result stays there: State.bond_group fetches it when asked)
+            st.set_bond_group_device(inv[st.bond_group_device()])
             st._bond_table = None
         st.position_generation += 1
         st.order_generation = getattr(st, "order_generation", 0) + 1

@@ -248,6 +248,40 @@ class State:
     def n_max(self):
         return self.N + self.n_ghost
 
+    # The bond members live in two places: a host array (HOOMD's snapshot layout, uint32 (n, 2)) and a device tensor
+    # (int64 (n, 2)). Whoever writes one invalidates the other; the copy across happens when the other one is asked for --
+    # the particle sorter re-indexes a million bonds on the device and the bond table is built there, so inside a run
+    # nothing travels (a sort used to cost two 8 MB transfers and two numpy passes, ~20 ms of idle GPU).
+    @property
+    def bond_group(self):
+        if self._bond_group_host is None:
+            import torch
+
+            self._bond_group_host = self._bond_group_dev.to(torch.int32).cpu().numpy().view(np.uint32).reshape(-1, 2)
+        return self._bond_group_host
+
+    @bond_group.setter
+    def bond_group(self, group):
+        self._bond_group_host = np.ascontiguousarray(group, dtype=np.uint32).reshape(-1, 2)
+        self._bond_group_dev = None
+
+    @property
+    def n_bonds(self):
+        g = self._bond_group_host if self._bond_group_host is not None else self._bond_group_dev
+        return int(g.shape[0])
+
+    def bond_group_device(self):
+        """The bond members as an int64 (n, 2) tensor on the state's device."""
+        if self._bond_group_dev is None:
+            import torch
+
+            self._bond_group_dev = torch.from_numpy(self._bond_group_host.astype(np.int64)).to(self.device).reshape(-1, 2)
+        return self._bond_group_dev
+
+    def set_bond_group_device(self, group):
+        self._bond_group_dev = group.reshape(-1, 2)
+        self._bond_group_host = None
+
     @property
     def typeid_host(self):
         return self.pos[: self.N, 3].cpu().numpy().view(np.int64).astype(np.int64) & 0xFFFFFFFF
@@ -281,7 +315,7 @@ class State:
             # scatter-add took 0.14 s for the 10^6 bonds of C3
             N = self.N
             dev = self.device
-            g = torch.from_numpy(self.bond_group.astype(np.int64)).to(dev).reshape(-1, 2)
+            g = self.bond_group_device()
             bt = torch.from_numpy(self.bond_typeid.astype(np.int64)).to(dev)
             nbnd = g.shape[0]
             # one entry per (bond, member); members that are ghosts here get their rows on their owner's rank
