@@ -353,6 +353,11 @@ class Pair(Force):
                 nl._fused_failures = getattr(nl, "_fused_failures", 0) + 1
                 if nl._fused_failures >= 2:
                     nl.fused = False
+                    nl._fused_auto_off = True   # (a particle sort switches it back on: Simulation.run)
+                if info["invalid_reason"] in (4, 5):
+                    # the members of some tile have drifted apart (a fast-diffusing fluid between two particle sorts):
+                    # ask for a sort now rather than at the sorter's next period
+                    nl._sort_wanted = True
                 nl.leave_fused_mode()
                 a.d_nlist = nl.nlist.data_ptr()
                 a.d_head_list = nl.head_list.data_ptr()

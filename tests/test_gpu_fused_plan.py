@@ -323,6 +323,40 @@ def test_fused_plan_limits_fall_back(oracle):
         assert nl.n_pairs == int(onl[0].sum())
 
 
+def test_unsorted_tiles_ask_for_a_particle_sort(oracle):
+    """Particles in random memory order with a sorter whose period is far away: the plan cannot be compiled from the cells
+    (the members of a tile are all over the box), the list-based path computes that step, and the run sorts the particles
+    at its next step instead of paying list-based rebuilds until the sorter's period comes round -- after which the plan
+    comes from the cells again (a DPD fluid gets there by diffusion between two sorts)."""
+    import azplugins_amd as azp
+
+    cfg = syn.config_plj_sc(20)
+    n = cfg["xyz"].shape[0]
+    L = cfg["L"]
+    perm = np.argsort(syn.hash64(6, np.arange(n, dtype=np.uint64), 0), kind="stable")
+    sim = azp.Simulation(device="cuda:0", seed=1)
+    sim.create_state_from_snapshot(azp.Snapshot.from_arrays(cfg["xyz"][perm], L, tag=perm.astype(np.uint32)))
+    nl = azp.nlist.Cell(buffer=0.4)
+    pot = azp.pair.PerturbedLennardJones(nlist=nl, default_r_cut=2.5)
+    pot.params[("A", "A")] = cfg["params"]
+    sim.operations.integrator = azp.Integrator(dt=0.0005, forces=[pot], methods=[azp.ConstantVolume()])
+    sim.operations.tuners.clear()
+    sorter = azp.ParticleSorter(trigger_period=100000)
+    sim.operations.tuners.append(sorter)
+    sim.run(0)
+    assert not nl._fused_active and nl._sort_wanted and sorter.num_sorts == 0
+    sim.run(3)
+    assert sorter.num_sorts == 1 and nl.fused and nl._fused_active and not nl._sort_wanted
+    assert pot.plan_info["valid"] == 1 and pot.plan_info["from_cells"] == 1
+    x = syn.pos4(sim.state.pos[:, :3].cpu().numpy())
+    box = oracle.make_box(L)
+    onl = oracle.build_nlist(x, box, 2.9)
+    f_ref = oracle.pair_forces(PLJ, x, box, onl, oracle.pack_pair_params(PLJ, cfg["params"]), 2.5, nthreads=8)
+    assert_close(np.c_[pot.forces, pot.energies], f_ref)
+    # the tags travelled with the particles
+    assert np.array_equal(np.sort(sim.state.tag.cpu().numpy().view(np.uint32)), np.arange(n, dtype=np.uint32))
+
+
 def test_fused_plan_through_the_api(oracle):
     """hoomd.azplugins-shaped run: the sole consumer of a Cell list gets its plan from the
     cells at every rebuild (no u32 list is ever filled), forces during an NVE run match the
