@@ -157,7 +157,7 @@ class PlanInfo(C.Structure):
         ("balanced", C.c_int32),
         ("core_radius", C.c_float),
         ("sure_radius", C.c_float),
-        ("_pad", C.c_int32),
+        ("max_member_cells", C.c_uint32),
     ]
 
 

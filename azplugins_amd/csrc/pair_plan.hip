@@ -867,7 +867,7 @@ extern "C" int azp_pair_plan_query(const azp_pair_plan* plan, azp_pair_plan_info
     info->head_id = reinterpret_cast<uint64_t>(p->head_ptr);
     info->core_radius = p->core_r;
     info->sure_radius = p->sure_r;
-    info->_pad = 0;
+    info->max_member_cells = p->max_member_cells;
     return AZP_SUCCESS;
     }
 

@@ -92,6 +92,7 @@ struct PairPlan
     uint32_t row_cap = 0;           // entries a compiled row can hold (fixed chunk capacity per slice)
     uint32_t max_row = 0;           // longest row seen (> row_cap: the caller retries with longer rows)
     uint16_t* d_raw = nullptr;      // raw rows (candidate number | class), scratch of the build
+    uint32_t max_member_cells = 0;  // build from cells: most distinct cells under the members of one tile (limit 128)
     size_t cap_raw = 0;
     // build option of plans from cells (azp_pair_plan_set_balance): the rows of a tile are handed to its
     // lanes in the order of their in-range lengths, so that each wave gets rows of similar length

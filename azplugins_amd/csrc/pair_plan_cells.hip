@@ -98,7 +98,7 @@ struct PlanCellsKArgs
     uint32_t* slice_Kphase; // [2][n_slices]: chunks covering class core; chunks holding only core / sure entries in every row
     uint64_t* slice_head;
     uint4* cnl;
-    uint32_t* flags;        // [0] sure radius, [1] invalid, [2] max staged set, [3] shell width, [5] longest row, [6] reason, [7] core radius
+    uint32_t* flags;        // [0] sure radius, [1] invalid, [2] max staged set, [3] shell width, [4] most member cells of a tile, [5] longest row, [6] reason, [7] core radius
     uint8_t* perm;          // balanced plans: lane -> member of the tile (n_tiles x 256); NULL: lane = member
     double r_list_max;
     BoxDev box;
@@ -547,6 +547,8 @@ __global__ void __launch_bounds__(PC_THREADS) plan_cells_kernel(const PlanCellsK
         {
         ncell_blk = s_ncells;
         n_mc = s_nmc;
+        if (tid == 0)
+            atomicMax(&a.flags[4], n_mc); // (reported: a caller that watches it re-sorts its particles before the limit is hit)
         if (ncell_blk > PC_MAXCELLS || n_mc > PC_MAXMC)
             {
             if (tid == 0)
@@ -1293,6 +1295,7 @@ int plan_build_from_cells(PairPlan& p, const azp_nlist_args& c, const azp_pair_a
         AZP_HIP_TRY(hipStreamSynchronize(s));
         p.max_stage = h_flags[2];
         p.max_row = h_flags[5];
+        p.max_member_cells = h_flags[4];
 #ifdef AZP_PLAN_CELLS_PROFILE
         fprintf(stderr, "plan_cells: %.1f candidate tests per particle, %.1f trips of the slowest lane per wave, per tile %.0f candidates, %.0f cells, %.2f batches\n",
                 16.0 * h_flags[8] / c.N, (double)h_flags[9] / (p.n_tiles * 4.0), (double)h_flags[10] / p.n_tiles, (double)h_flags[11] / p.n_tiles,

@@ -334,6 +334,13 @@ class Pair(Force):
             self._plan_valid = bool(info["valid"])
             if info["valid"]:
                 nl._fused_failures = 0
+                # the members of the tiles drift apart between two particle sorts; past 128 cells under one tile the
+                # compile is refused: ask for a sort when that comes near (and the count has grown since the last sort)
+                mc = int(info.get("max_member_cells", 0))
+                if getattr(nl, "_member_cells_key", None) != getattr(self._state, "order_generation", 0):
+                    nl._member_cells_key, nl._member_cells_sorted = getattr(self._state, "order_generation", 0), mc
+                if mc > 108 and mc > 1.15 * nl._member_cells_sorted:
+                    nl._sort_wanted = True
                 nl._plan_row_capacity = max((int(info["max_row"] * 1.06) + 4 + 7) // 8 * 8, 32)
                 nl._fused_counts_ready = True
                 self._plan_ids = (info["list_id"], info["head_id"])

@@ -252,7 +252,10 @@ typedef struct azp_pair_plan_info
     float core_radius;           /* row phases (one particle type): entries outside row class "core" were at least this
                                     far apart when the plan was built; 0: no such class */
     float sure_radius;           /* ... entries of row class "sure" at most this far apart; 0: no such class */
-    int32_t _pad;
+    uint32_t max_member_cells;   /* azp_pair_plan_build_from_cells, cells of the full list radius: the largest number of
+                                    distinct cells the members of one tile sit in (beyond 128 the plan is refused with
+                                    reason 4). It grows as the particles diffuse away from their sorted order: a caller
+                                    that re-sorts them when it approaches the limit never sees the refusal */
     } azp_pair_plan_info;
 
 int azp_pair_plan_create(azp_pair_plan** out);
