@@ -16,6 +16,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("which", nargs="?", default="c4")
 ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--settle-ms", type=float, default=80.0)
+ap.add_argument("--sort", action="store_true", help="Hilbert-sort the particles first, as an MD run does every 200 steps (the synthetic "
+                                                     "configurations come cell by cell: looser tiles)")
 args = ap.parse_args()
 cfg = syn.config_dpd() if args.which == "c4" else syn.config_tpm()
 sim = azp.Simulation(device="cuda:0", seed=cfg.get("seed", 1))
@@ -29,6 +31,9 @@ else:
 pot.params[("A", "A")] = cfg["params"]
 sim.operations.integrator = azp.Integrator(dt=cfg.get("dt", 0.005), forces=[pot])
 pot.use_plan = True
+sim.operations.tuners.clear()
+if args.sort:
+    azp.ParticleSorter().sort(sim)
 sim.run(0)
 
 
