@@ -117,6 +117,8 @@ def test_fused_plan_parity(oracle, name, T, mode):
     f_ref, v_ref = oracle.pair_forces(name, pos, box, nl, params, r_cut, r_on, mode, ntypes=T, virial=True)
     (f_gpu, v_gpu), info = fused_forces(name, pos, (L,), params, r_cut, r_buff, ntypes=T, mode=mode, r_on=r_on, virial=True)
     assert info["valid"] == 1 and info["from_cells"] == 1
+    if info["cell_subdivision"] == 1:
+        assert 0 < info["max_member_cells"] <= 128  # (what a run watches to re-sort its particles before the compiler refuses)
     assert_close(f_gpu, f_ref)
     assert_close(v_gpu, v_ref, what="virial")
     # the rows are a superset of the exact list by a hair at most (single-precision test, 1e-5 margin)

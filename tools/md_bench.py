@@ -18,7 +18,7 @@ from azplugins_amd import synthetic as syn
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=400)
 ap.add_argument("--kT", type=float, default=1.0)
-ap.add_argument("--dt", type=float, default=0.005)
+ap.add_argument("--dt", type=float, default=None, help="default 0.005 (c3: 0.002, c5: 0.004)")
 ap.add_argument("--ncell", type=int, default=64)
 ap.add_argument("--no-plan", action="store_true")
 ap.add_argument("--sort-period", type=int, default=200, help="re-index the particles every this many steps (0 = never)")
@@ -28,6 +28,8 @@ ap.add_argument("--workload", default="ns", help="ns: the north-star liquid (Per
                                                  "PerturbedLJ + DoubleWell bonds")
 ap.add_argument("--buffer", type=float, default=None, help="neighbor-list buffer r_buff (default: the workload's 0.4; HOOMD users tune it)")
 args = ap.parse_args()
+if args.dt is None:
+    args.dt = {"c3": 0.002, "c5": 0.004}.get(args.workload, 0.005)
 
 cfg = {"ns": lambda: syn.config_north_star(args.ncell), "c3": syn.config_chains, "c5": syn.config_tpm, "c4": syn.config_dpd}[args.workload]()
 N = cfg["xyz"].shape[0]

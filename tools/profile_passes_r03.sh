@@ -28,8 +28,8 @@ tail -4 $O/md_bench.log
 python3 tools/md_bench.py --steps 300 > $O/md_bench_noprof.log 2>&1
 tail -4 $O/md_bench_noprof.log
 python3 tools/md_bench.py --steps 300 --buffer 0.7 > $O/md_bench_buffer07.log 2>&1
-rocprofv3 --kernel-trace --stats -d $O/c3_stats --output-format csv -- python3 tools/md_bench.py --workload c3 --steps 300 --dt 0.002 > $O/c3_md.log 2> $O/c3_md.err
-python3 tools/md_bench.py --workload c3 --steps 300 --dt 0.002 > $O/c3_md_noprof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/c3_stats --output-format csv -- python3 tools/md_bench.py --workload c3 --steps 300 > $O/c3_md.log 2> $O/c3_md.err
+python3 tools/md_bench.py --workload c3 --steps 300 > $O/c3_md_noprof.log 2>&1
 tail -4 $O/c3_md_noprof.log
 rocprofv3 --kernel-trace --stats -d $O/c4_stats --output-format csv -- python3 tools/xtiled_probe.py c4 > $O/c4.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/c5_stats --output-format csv -- python3 tools/xtiled_probe.py c5 > $O/c5.log 2>&1
