@@ -68,6 +68,10 @@ if args.sort_period:
     sim.operations.tuners[0].host_seconds = 0.0
     sim.operations.tuners[0].num_sorts = 0
     sim.run(10)
+# likewise the HOOMD-format list (built here once: the path a refused plan compile falls back to drags in a handful of
+# framework kernels, tens of ms of module loading the first time)
+_ = nl.size
+sim.run(10)
 if args.tune_buffer:
     tuner = azp.tune.NeighborListBuffer(nl)
     best = tuner.tune(sim)
