@@ -265,7 +265,12 @@ class Cell(NeighborList):
         if box.is_triclinic:
             raise _lib.AzpError("Cell neighbor list: triclinic boxes are not supported yet")
         a.ntypes = ntypes
-        rlistsq = torch.from_numpy(np.ascontiguousarray((rl * rl).reshape(-1))).to(dev)
+        # (kept across rebuilds while the cutoffs stand: a host-to-device copy from pageable memory waits for the stream)
+        key = (self._consumer_version, self.buffer, str(dev), ntypes)
+        if getattr(self, "_rlistsq_key", None) != key:
+            self._rlistsq_dev = torch.from_numpy(np.ascontiguousarray((rl * rl).reshape(-1))).to(dev)
+            self._rlistsq_key = key
+        rlistsq = self._rlistsq_dev
         a.d_rlistsq = rlistsq.data_ptr()
         stream = torch.cuda.current_stream(dev).cuda_stream
         self._rl_max, self._box_at_build = rl_max, box
