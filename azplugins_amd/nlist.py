@@ -120,10 +120,11 @@ class NeighborList:
 class Cell(NeighborList):
     """Cell-list neighbor list (full storage, as HOOMD's GPU pair kernels use)."""
 
-    # azp_nlist_bin (counting sort in libazp) instead of the framework's sort pipeline. Off by default
-    # (AZP_NATIVE_BINNING=1 turns it on): its five kernels take 63 us against the pipeline's ~130 us + launch gaps,
-    # but a 300-step MD run of the north star came out SLOWER with it (0.49 vs 0.43 ms per step, twice each on one
-    # box) for a reason the kernel trace does not show; kept for callers without the framework, tested for equality.
+    # azp_nlist_bin (counting sort in libazp) instead of the framework's sort pipeline: by default (None) where the cells
+    # number more than 2^16 (16-bit keys do not hold them and the framework sort needs four radix passes), AZP_NATIVE_BINNING=1 / 0
+    # forces it on / off. For the north star's 2^15 cells the two are equal in a 300-step MD run (0.402-0.403 against
+    # 0.403-0.406 ms per step at the end of round 3; an earlier version of the library's kernels measured slower); kept also for
+    # callers without the framework, tested for equality with the stable sort.
     native_binning = {"0": False, "1": True}.get(os.environ.get("AZP_NATIVE_BINNING", ""), None)  # None: when the cells number more than 2^16 (the framework sort then needs four radix passes)
 
     def compute(self, state, force=False, compact=False):
