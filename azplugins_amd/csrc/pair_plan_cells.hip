@@ -14,7 +14,7 @@
 //      a row that wraps through the periodic boundary is two runs);
 //   2. the candidates are staged in LDS in batches of 1,024 (single-precision positions
 //      relative to the tile's reference particle); every thread walks the runs of its member
-//      through the batch, one candidate per step. An accepted candidate is appended to the
+//      through the batch, four candidates per trip (packed FP32 math). An accepted candidate is appended to the
 //      member's raw row (candidate number | class, 2 B, global scratch laid out [entry][member]
 //      so that the 64 lanes of a wave write and later read one cache line); a second walk over
 //      the finished row counts its classes and marks its candidates in a bitmap;
@@ -31,6 +31,9 @@
 // with a 1e-5 margin on r_list^2 plus a bound on the rounding of the staged coordinates, see rl_extra):
 // extra entries are buffer entries the force kernel's exact
 // FP64 cutoff test ignores. Classes are conservative exactly as in pair_plan.hip.
+//
+// A second form of phases 0 - 2 works on cells of HALF the list radius (template parameter HALF, azp_nlist_args.
+// cell_subdivision = 2; see PC_BATCH_H below): exact, 0.39 x the candidate tests, not faster -- off by default.
 //
 // Limits (the plan is marked invalid and the caller falls back to the list-based path): the
 // members of a tile sit in more than 128 cells, or the cells around them number more than 512
